@@ -1,0 +1,164 @@
+"""Pins the CPU oracle to the reference: every oracle function against golden vectors that
+tools/gen_golden.py produced by running the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from codlad_amd import synth
+from oracle import denoiser, sampler, schedule, vae_decode
+from tests import cases
+
+
+def g(name):
+    return np.load(cases.npz_path(name))
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth.denoiser_state_dict(cases.WEIGHT_SEED)
+
+
+@pytest.mark.parametrize("T", ["10", "100", "250"])
+def test_g1_schedule(T):
+    gold = g(f"g1_schedule_{T}")
+    mine = schedule.make_schedule(T)
+    assert np.array_equal(mine["timestep_map"], gold["timestep_map"])
+    for k in gold.files:
+        if k != "timestep_map":
+            np.testing.assert_array_equal(mine[k], gold[k], err_msg=k)  # float64, bit-exact
+
+
+@pytest.mark.parametrize("name", list(cases.DENOISER_CASES))
+def test_g2_forward(sd, name):
+    L, B, seed = cases.DENOISER_CASES[name]
+    gold = g(f"g2_forward_{name}")
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, m = denoiser.batch_to_dense(batch)
+    taps = {}
+    out = denoiser.forward(sd, x, t, cg_xyz, cg_z, mask, taps=taps)
+    assert torch.equal(taps["E_idx"], torch.from_numpy(gold["E_idx"]))      # int64: exact
+    assert rel_err(out, gold["out"]) < 2e-6
+    if "h_E0" in gold.files:
+        nn_ = gold["h_E0"].shape[1]
+        assert rel_err(taps["h_E0"][:, :nn_], gold["h_E0"]) < 2e-6
+        for l in range(3):
+            assert rel_err(taps[f"enc{l}_hV"], gold[f"enc{l}_hV"]) < 2e-6
+            assert rel_err(taps[f"enc{l}_hE"][:, :nn_], gold[f"enc{l}_hE"]) < 2e-6
+            assert rel_err(taps[f"dec{l}_hV"], gold[f"dec{l}_hV"]) < 2e-6
+    # the reference's doubled "CFG" batch (test.py:505) does not change the first half
+    assert float(gold["max_abs_diff_doubled"]) < 1e-5
+
+
+def test_g2_forward_padded(sd):
+    name, lengths, seed = cases.PADDED_CASE
+    gold = g(f"g2_forward_{name}")
+    batch, x, t, mask = cases.padded_inputs(lengths, seed)
+    cg_z, cg_xyz, m = denoiser.batch_to_dense(batch)
+    assert torch.equal(m, mask)
+    taps = {}
+    out = denoiser.forward(sd, x, t, cg_xyz, cg_z, mask, taps=taps)
+    assert torch.equal(taps["E_idx"], torch.from_numpy(gold["E_idx"]))
+    assert rel_err(out, gold["out"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", list(cases.LOOP_CASES))
+def test_g3_loop(sd, name):
+    L, B, seed, T = cases.LOOP_CASES[name]
+    if T > 10:
+        pytest.skip("100-step CPU loop: covered by test_g3_loop_100 (slow marker)")
+    gold = g(f"g3_loop_{name}")
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, _ = denoiser.batch_to_dense(batch)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    x, traj = sampler.p_sample_loop(sd, T, z, eps, cg_xyz, cg_z, mask, return_traj=True)
+    for k in range(T):
+        assert rel_err(traj[k], gold["traj"][k]) < 5e-6, k
+    assert rel_err(x, gold["sample"]) < 5e-6
+    # hoisting the step-invariant CA features out of the loop changes nothing
+    xh = sampler.p_sample_loop(sd, T, z, eps, cg_xyz, cg_z, mask, hoist_features=True)
+    assert torch.equal(x, xh)
+
+
+def test_g3_loop_100(sd):
+    L, B, seed, T = cases.LOOP_CASES["L87_B1_T100"]
+    gold = g("g3_loop_L87_B1_T100")
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, _ = denoiser.batch_to_dense(batch)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    x, traj = sampler.p_sample_loop(sd, T, z, eps, cg_xyz, cg_z, mask, hoist_features=True,
+                                    return_traj=True)
+    for j, k in enumerate(range(9, 100, 10)):
+        assert rel_err(traj[k], gold["traj_every10"][j]) < 2e-5, k
+    assert rel_err(x, gold["sample"]) < 2e-5
+
+
+@pytest.mark.parametrize("vae_type,dataname", [("N6", "PED"), ("K3", "PDB"), ("K4", "Atlas")])
+def test_g4_vq(vae_type, dataname):
+    gold = g(f"g4_vq_{vae_type}")
+    vsd = synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED)
+    mean, std = synth.norm_stats(dataname, vae_type)
+    x = synth.gaussian((4, 77, 3), 123 + len(dataname))
+    lat = vae_decode.denormalise(x, mean, std)
+    assert torch.equal(lat, torch.from_numpy(gold["latent"]))
+    zq, idx = vae_decode.vq_lookup(lat, vae_decode.codebook_of(vsd))
+    assert torch.equal(idx, torch.from_numpy(gold["idx"]))                   # bit-exact indices
+    assert torch.equal(zq, torch.from_numpy(gold["z_q"]))
+
+
+def _vae_sd(vae_type, dataname, real_c2=False):
+    vsd = synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED, c2_like_map_out=real_c2)
+    if real_c2:
+        w = g("c2_decoder_weights")
+        for k in w.files:
+            vsd[k] = torch.from_numpy(w[k])
+    return vsd
+
+
+@pytest.mark.parametrize("name", list(cases.DECODER_CASES) + ["realC2_L87_B2"])
+def test_g5_decoder(name):
+    real = name.startswith("realC2")
+    L, B, seed, vae_type = cases.DECODER_CASES["N6_L87_B2" if real else name]
+    gold = g(f"g5_decode_{name}")
+    prot, batch, latent, dataname = cases.decoder_inputs(L, B, seed, vae_type)
+    vsd = _vae_sd(vae_type, dataname, real)
+    idx, ic = vae_decode.latent_decode(vsd, latent, batch, angle=vae_type in ("K3", "K4"))
+    if "idx" in gold.files:
+        assert torch.equal(idx, torch.from_numpy(gold["idx"]))
+    assert rel_err(ic, gold["ic_recon"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", list(cases.DECODER_CASES))
+def test_g6_ic_to_xyz(name):
+    L, B, seed, vae_type = cases.DECODER_CASES[name]
+    prot, batch, latent, dataname = cases.decoder_inputs(L, B, seed, vae_type)
+    ic = torch.from_numpy(g(f"g5_decode_{name}")["ic_recon"]).reshape(-1, L, 13, 3)
+    og = batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)
+    xyz = vae_decode.ic_to_xyz(og, ic, prot["info"])
+    gold = torch.from_numpy(g(f"g6_xyz_{name}")["xyz"])
+    assert xyz.shape == gold.shape
+    assert float((xyz - gold).abs().max()) < 1e-4      # Angstrom
+
+
+def test_g7_end_to_end_T10(sd):
+    name = "PED_N6_L46_B2_T10"
+    L, B, seed, T, vae_type, dataname = cases.E2E_CASES[name]
+    gold = g(f"g7_e2e_{name}")
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, _ = denoiser.batch_to_dense(batch)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    samples = sampler.p_sample_loop(sd, T, z, eps, cg_xyz, cg_z, mask)
+    assert rel_err(samples, gold["samples"]) < 5e-6
+    mean, std = synth.norm_stats(dataname, vae_type)
+    vsd = synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED)
+    idx, ic = vae_decode.latent_decode(vsd, vae_decode.denormalise(samples, mean, std), batch)
+    assert torch.equal(idx, torch.from_numpy(gold["idx"]))
+    xyz = vae_decode.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4),
+                               ic.reshape(-1, L, 13, 3), prot["info"])
+    rmsd = float(((xyz - torch.from_numpy(gold["xyz"])) ** 2).sum(-1).mean().sqrt())
+    assert rmsd < 1e-4
