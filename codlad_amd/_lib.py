@@ -1,0 +1,111 @@
+"""ctypes binding of libcodlad_hip.so (include/codlad_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+`import torch` happens first so that the library's libamdhip64.so.7 dependency resolves to the
+HIP runtime PyTorch already loaded (same SONAME) - streams and device pointers are then shared.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcodlad_hip.so")
+
+P = C.c_void_p
+
+
+class EncLayer(C.Structure):
+    _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c")] + \
+               [("Win", P * 4), ("Wout", P * 4)] + \
+               [(n, P) for n in ("b1", "b2", "b3", "b11", "b12", "b13", "b_in", "b_out")]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W1a", "W1v", "TS")] + \
+               [("Win", P * 4), ("Wout", P * 4)] + \
+               [(n, P) for n in ("b1", "b2", "b3", "b_in", "b_out")]
+
+
+class DenoiserWeights(C.Structure):
+    _fields_ = [(n, P) for n in ("freqs", "rbf_mu", "t_w0", "t_b0", "t_w2", "t_b2")] + \
+               [("ada_w", P * 7), ("ada_b", P * 7)] + \
+               [(n, P) for n in ("x_in_w", "x_in_b", "pos_w", "pos_b", "edge_wT", "norm_w", "norm_b",
+                                 "We_wT", "We_b", "out_w", "out_b")] + \
+               [("enc", EncLayer * 3), ("dec", DecLayer * 3)]
+
+
+class Workspace(C.Structure):
+    _fields_ = [(n, P) for n in ("hV", "hVenc", "S", "PQ", "hE")]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("angle", C.c_int), ("map_out_w", P), ("map_out_b", P), ("res_embed", P)] + \
+               [(n, P * 4) for n in ("inv0_w", "inv0_b", "inv1_w", "inv1_b", "dist_w", "dist_b",
+                                     "dense1_w", "dense1_b", "dense3_w", "dense3_b")] + \
+               [(n, P) for n in ("bb_dist", "sc_dist", "bb_ang1_w", "bb_ang1_b", "bb_ang3_w", "bb_ang3_b",
+                                 "sc_angle_emb", "sc_ang1_w", "sc_ang1_b", "sc_ang3_w", "sc_ang3_b",
+                                 "bb_tor1_w", "bb_tor1_b", "bb_tor3_w", "bb_tor3_b")] + \
+               [(n, P * 4) for n in ("tor1_w", "tor1_b", "tor3_w", "tor3_b")] + \
+               [(n, P) for n in ("fin1_w", "fin1_b", "fin3_w", "fin3_b")]
+
+
+_SIGS = {
+    "codlad_abi_version": (C.c_int, []),
+    "codlad_last_error": (C.c_char_p, []),
+    "codlad_pack_block_host": (None, [P, C.c_int, C.c_float, P]),
+    "codlad_features_prepass": (C.c_int, [C.POINTER(DenoiserWeights), P, P, C.c_int, C.c_int, P, P, P]),
+    "codlad_step_mods": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P]),
+    "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, P, P,
+                                          C.POINTER(Workspace), P]),
+    "codlad_ddpm_update": (C.c_int, [P, P, P, P, C.c_int, P, P]),
+    "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, P, P, P, C.c_int,
+                                     C.POINTER(Workspace), P]),
+    "codlad_vq_lookup": (C.c_int, [P, C.c_int, P, P, P, C.c_int, P, P, P, P]),
+    "codlad_ic_decode": (C.c_int, [C.POINTER(DecoderWeights), P, P, P, P, P, C.c_int, P, P, P]),
+    "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
+    "codlad_selftest_gemm128": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -m codlad_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the only implementation of this path "
+                "(build it with `python -m codlad_amd.build`)")
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.codlad_abi_version() != 1:
+            raise RuntimeError("libcodlad_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().codlad_last_error().decode() or "unknown error"
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "non-contiguous tensor handed to the C ABI"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,39 @@
+// Host-side plumbing of libcodlad_hip.so: error reporting and the weight-block packer.
+#include "common.h"
+#include "../../include/codlad_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void codlad_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int codlad_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        codlad_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int codlad_abi_version(void) { return CODLAD_ABI_VERSION; }
+
+extern "C" const char *codlad_last_error(void) { return g_err; }
+
+extern "C" void codlad_pack_block_host(const float *src, int ld, float scale, float *dst) {
+    for (int b = 0; b < 4; ++b)
+        for (int r = 0; r < 16; ++r)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int bo = 0; bo < 4; ++bo) {
+                    const int row = 32 * bo + (lane & 31);
+                    const int col = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    dst[((16 * b + r) * 64 + lane) * 4 + bo] = scale * src[(size_t)row * ld + col];
+                }
+}

@@ -1,0 +1,500 @@
+// Per-step kernels of the mpnn_diffusion denoiser for gfx950 (SURVEY.md 8a rows 5-7 + row 2).
+//
+// Algebra used (results equal the reference's up to fp32 summation order):
+//   W1 @ [h_V_i | h_E_ij | h_V_j] = W1a @ h_V_i + W1e @ h_E_ij + W1c @ h_V_j
+//     -> the two node terms are projected once per node (P, Q) and gathered per edge, only
+//        the h_E term is a per-edge contraction;
+//   sum_k (W3 @ g_k + b3) = W3 @ (sum_k g_k) + K * b3
+//     -> the third message layer runs once per node on the neighbour sum S.
+// Per edge this leaves 2 (message) or 3 (edge update) 128x128 contractions, all on
+// v_mfma_f32_32x32x2_f32 through the register chain of common.h.
+#include "common.h"
+#include "../../include/codlad_hip.h"
+
+#define HD 128
+
+// ---------------------------------------------------------------------------------------------
+// Edge kernels: one wave = one node = up to 64 neighbour columns (two 32-column passes).
+// ---------------------------------------------------------------------------------------------
+struct EdgeArgs {
+    const int4 *node_info;
+    const int32_t *E_idx;  // [n_snodes][64]
+    const float *hE_in;    // [rows][64][128]
+    int in_by_src;         // 1: rows indexed by structure node (h_E0), 0: by sample node
+    float *hE_out;         // edge update only
+    const float *P, *Q;    // [n_nodes][128]: own-node term (+bias), neighbour term
+    const float *W1, *W2, *W3;
+    const float *b2, *b3;
+    const float *mods3;    // edge update: shift3, scale3, gate3 (3 x 128)
+    float *S;              // message: [n_nodes][128]
+    int n_nodes;
+};
+
+template <bool EDGE_UPDATE>
+__global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.n_nodes) return;
+    const int h = lane >> 5, c = lane & 31;
+    const int4 info = a.node_info[n];
+    const int src = info.x, base = info.y, K = info.z;
+    const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * (64 * HD);
+    const float *Prow = a.P + (size_t)n * HD;
+
+    for (int half = 0; half < 2; ++half) {
+        if (32 * half >= K) break;
+        const int col = 32 * half + c;
+        const bool valid = col < K;
+        const int colc = valid ? col : 0;
+        const int j = a.E_idx[(size_t)src * 64 + colc];
+
+        Tile x, acc;
+        tile_load_row(x, rows + (size_t)colc * HD, h);
+        tile_load_row(acc, Prow, h);
+        tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
+        gemm128(acc, x, a.W1, lane);
+        tile_gelu(acc);
+        tile_load_row(x, a.b2, h);
+        gemm128(x, acc, a.W2, lane);
+        tile_gelu(x);
+
+        if (!EDGE_UPDATE) {
+            // S[n] = sum over the valid columns; each half reduces its 32 lanes, the second
+            // half adds to what the first one stored (same wave, program order)
+            float *Srow = a.S + (size_t)n * HD;
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = valid ? x.b[bo][r] : 0.f;
+                    v += __shfl_xor(v, 1, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 16, 64);
+                    x.b[bo][r] = v;
+                }
+            if (c == 0) {
+                if (half) tile_add_row(x, Srow, h);
+                tile_store_row(x, Srow, h);
+            }
+        } else {
+            tile_load_row(acc, a.b3, h);
+            gemm128(acc, x, a.W3, lane);
+            tile_add_row(acc, rows + (size_t)colc * HD, h);  // residual: h_E + message
+            tile_layernorm(acc, 1e-6f);
+            tile_modulate(acc, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);
+            if (valid) tile_store_row(acc, a.hE_out + ((size_t)n * 64 + col) * HD, h);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node kernel: one wave = 32 nodes (columns).
+//   MODE_IN : h_V = x_in(x)
+//   MODE_UPD: h_V = mod2(LN(v + FFN(v))),  v = mod1(LN(h_V + (W3 @ S + K b3) / 30))
+// then up to four 128x128 projections of the new h_V for the next edge kernels.
+// ---------------------------------------------------------------------------------------------
+struct NodeArgs {
+    const int4 *node_info;
+    int n_nodes;
+    const float *x, *x_in_w, *x_in_b;  // MODE_IN
+    const float *S;                    // MODE_UPD
+    float *hV;
+    const float *W3, *b3;
+    const float *mods;                 // shift1, scale1, gate1, shift2, scale2, gate2
+    const float *Win[4], *Wout[4];
+    const float *b_in, *b_out;
+    int n_proj;
+    const float *proj_w[4];
+    const float *proj_b[4];            // may be null
+    float *proj_out[4];
+    int proj_flags[4];                 // bit0: input = h_V + h_Venc; bit1: += TS[z]
+    const float *TS;                   // [30][128]
+    const float *hVenc_in;
+    float *hVenc_out;                  // if set: also store the new h_V here (h_Venc := h_V)
+    int venc_is_self;                  // h_Venc == new h_V (first decoder layer's Q)
+};
+
+template <bool MODE_UPD>
+__global__ __launch_bounds__(64, 1) void node_kernel(NodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, c = lane & 31;
+    const int node = blockIdx.x * 32 + c;
+    const bool valid = node < a.n_nodes;
+    const int nc = valid ? node : a.n_nodes - 1;
+    const int4 info = a.node_info[nc];
+
+    Tile v;
+    if (!MODE_UPD) {
+        const float x0 = a.x[nc * 3 + 0], x1 = a.x[nc * 3 + 1], x2 = a.x[nc * 3 + 2];
+        tile_load_row(v, a.x_in_b, h);
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float *wr = a.x_in_w + f * 3;
+                v.b[bo][r] += fmaf(x2, wr[2], fmaf(x1, wr[1], x0 * wr[0]));
+            }
+    } else {
+        Tile s, t;
+        tile_load_row(s, a.S + (size_t)nc * HD, h);
+        tile_load_row(t, a.b3, h);
+        const float kf = (float)info.z;
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) t.b[bo] *= kf;
+        gemm128(t, s, a.W3, lane);
+        tile_load_row(v, a.hV + (size_t)nc * HD, h);
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v.b[bo][r] += t.b[bo][r] / 30.0f;
+        tile_layernorm(v, 1e-6f);
+        tile_modulate(v, a.mods, a.mods + HD, a.mods + 2 * HD, h);
+        // position-wise FFN 128 -> 512 -> 128 in four 128-wide hidden chunks
+        tile_load_row(t, a.b_out, h);
+#pragma unroll 1
+        for (int ch = 0; ch < 4; ++ch) {
+            tile_load_row(s, a.b_in + ch * HD, h);
+            gemm128(s, v, a.Win[ch], lane);
+            tile_gelu(s);
+            gemm128(t, s, a.Wout[ch], lane);
+        }
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) v.b[bo] += t.b[bo];
+        tile_layernorm(v, 1e-6f);
+        tile_modulate(v, a.mods + 3 * HD, a.mods + 4 * HD, a.mods + 5 * HD, h);
+    }
+    if (valid) {
+        tile_store_row(v, a.hV + (size_t)node * HD, h);
+        if (a.hVenc_out) tile_store_row(v, a.hVenc_out + (size_t)node * HD, h);
+    }
+
+#pragma unroll 1
+    for (int p = 0; p < a.n_proj; ++p) {
+        Tile in = v, out;
+        const int fl = a.proj_flags[p];
+        if (fl & 1) {
+            if (a.venc_is_self) {
+#pragma unroll
+                for (int bo = 0; bo < 4; ++bo) in.b[bo] += v.b[bo];
+            } else {
+                tile_add_row(in, a.hVenc_in + (size_t)nc * HD, h);
+            }
+        }
+        if (a.proj_b[p]) tile_load_row(out, a.proj_b[p], h);
+        else tile_zero(out);
+        if (fl & 2) tile_add_row(out, a.TS + (size_t)info.w * HD, h);
+        gemm128(out, in, a.proj_w[p], lane);
+        if (valid) tile_store_row(out, a.proj_out[p] + (size_t)node * HD, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FinalLayer (latent_model.py:31-35) + ancestral DDPM update (gaussian_diffusion.py:303-367,446).
+// One thread per node.
+// ---------------------------------------------------------------------------------------------
+struct FinalArgs {
+    const float *hV;
+    const float *mods;  // shift, scale (2 x 128)
+    const float *out_w, *out_b;
+    int n_nodes;
+    float *logits;      // [n][6] or null
+    float *x;           // in/out [n][3] (update mode)
+    const float *noise; // [n][3]
+    const float *coef;  // device [8]
+};
+
+__global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.n_nodes) return;
+    const float4 *row = reinterpret_cast<const float4 *>(a.hV + (size_t)n * HD);
+    float s = 0.f;
+    for (int i = 0; i < 32; ++i) {
+        const float4 v = row[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = s * (1.0f / 128.0f);
+    float var = 0.f;
+    for (int i = 0; i < 32; ++i) {
+        const float4 v = row[i];
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + 1e-6f);
+    float o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = 0.f;
+    const float *shift = a.mods, *scale = a.mods + HD;
+    for (int i = 0; i < 32; ++i) {
+        const float4 v = row[i];
+        const float y[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = 4 * i + e;
+            const float m = ((y[e] - mean) * rstd) * (1.0f + scale[f]) + shift[f];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = fmaf(m, a.out_w[k * HD + f], o[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] += a.out_b[k];
+    if (a.logits) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.logits[(size_t)n * 6 + k] = o[k];
+        return;
+    }
+    const float c_recip = a.coef[0], c_recipm1 = a.coef[1], pc1 = a.coef[2], pc2 = a.coef[3];
+    const float min_log = a.coef[4], max_log = a.coef[5], nonzero = a.coef[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float xt = a.x[(size_t)n * 3 + k];
+        const float frac = (o[3 + k] + 1.0f) / 2.0f;
+        const float logvar = frac * max_log + (1.0f - frac) * min_log;
+        const float x0 = c_recip * xt - c_recipm1 * o[k];
+        const float mean_ = pc1 * x0 + pc2 * xt;
+        a.x[(size_t)n * 3 + k] = mean_ + nonzero * expf(0.5f * logvar) * a.noise[(size_t)n * 3 + k];
+    }
+}
+
+// stand-alone DDPM update on a model output [n][6]
+__global__ void ddpm_kernel(const float *x, const float *out, const float *noise, float c_recip,
+                            float c_recipm1, float pc1, float pc2, float min_log, float max_log,
+                            float nonzero, int n_nodes, float *x_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes * 3) return;
+    const int n = i / 3, k = i - 3 * n;
+    const float xt = x[i];
+    const float frac = (out[n * 6 + 3 + k] + 1.0f) / 2.0f;
+    const float logvar = frac * max_log + (1.0f - frac) * min_log;
+    const float x0 = c_recip * xt - c_recipm1 * out[n * 6 + k];
+    const float mean_ = pc1 * x0 + pc2 * xt;
+    x_out[i] = mean_ + nonzero * expf(0.5f * logvar) * noise[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Timestep embedding + all adaLN heads, one workgroup per timestep (row 3).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mods_kernel(codlad_denoiser_weights w, const int64_t *tv,
+                                                  float *mods) {
+    __shared__ float emb[256];
+    __shared__ float hid[HD];
+    __shared__ float sc[HD];
+    const int tid = threadIdx.x;
+    const float t = (float)tv[blockIdx.x];
+    {
+        const int k = tid & 127;
+        const float arg = t * w.freqs[k];
+        emb[tid] = tid < 128 ? cosf(arg) : sinf(arg);
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float acc = 0.f;
+        const float *wr = w.t_w0 + tid * 256;
+        for (int k = 0; k < 256; ++k) acc = fmaf(emb[k], wr[k], acc);
+        acc += w.t_b0[tid];
+        hid[tid] = acc / (1.0f + expf(-acc));
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float acc = 0.f;
+        const float *wr = w.t_w2 + tid * HD;
+        for (int k = 0; k < HD; ++k) acc = fmaf(hid[k], wr[k], acc);
+        acc += w.t_b2[tid];
+        sc[tid] = acc / (1.0f + expf(-acc));  // SiLU(c) feeds every adaLN head
+    }
+    __syncthreads();
+    float *out = mods + (size_t)blockIdx.x * CODLAD_MODS_PER_STEP;
+    int off = 0;
+    for (int hd = 0; hd < 7; ++hd) {
+        const int rows = hd < 3 ? 9 * HD : (hd < 6 ? 6 * HD : 2 * HD);
+        for (int r = tid; r < rows; r += 256) {
+            const float *wr = w.ada_w[hd] + (size_t)r * HD;
+            float acc = 0.f;
+            for (int k = 0; k < HD; ++k) acc = fmaf(sc[k], wr[k], acc);
+            out[off + r] = acc + w.ada_b[hd][r];
+        }
+        off += rows;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static inline int mods_offset(int head) {  // enc0..2, dec0..2, final
+    return head < 3 ? head * 9 * HD : (head < 6 ? 27 * HD + (head - 3) * 6 * HD : 45 * HD);
+}
+
+static void launch_edge(bool update, const EdgeArgs &ea, hipStream_t st) {
+    dim3 grid((ea.n_nodes + 3) / 4), block(256);
+    if (update) hipLaunchKernelGGL(edge_kernel<true>, grid, block, 0, st, ea);
+    else hipLaunchKernelGGL(edge_kernel<false>, grid, block, 0, st, ea);
+}
+
+static void launch_node(bool upd, const NodeArgs &na, hipStream_t st) {
+    dim3 grid((na.n_nodes + 31) / 32), block(64);
+    if (upd) hipLaunchKernelGGL(node_kernel<true>, grid, block, 0, st, na);
+    else hipLaunchKernelGGL(node_kernel<false>, grid, block, 0, st, na);
+}
+
+// One denoiser forward up to (not including) the final layer: leaves h_V in ws->hV.
+static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
+                            int n_nodes, const int32_t *E_idx, const float *h_E0, const float *x,
+                            const float *mods_t, const codlad_workspace *ws, hipStream_t st) {
+    const int4 *ni = reinterpret_cast<const int4 *>(node_info);
+    const size_t NS = (size_t)n_nodes * HD;
+    float *PQ0 = ws->PQ, *PQ1 = ws->PQ + NS, *PQ2 = ws->PQ + 2 * NS, *PQ3 = ws->PQ + 3 * NS;
+
+    // h_V = x_in(x); P/Q for encoder layer 0's message
+    {
+        NodeArgs na = {};
+        na.node_info = ni; na.n_nodes = n_nodes;
+        na.x = x; na.x_in_w = w->x_in_w; na.x_in_b = w->x_in_b; na.hV = ws->hV;
+        na.n_proj = 2;
+        na.proj_w[0] = w->enc[0].W1a; na.proj_b[0] = w->enc[0].b1; na.proj_out[0] = PQ0;
+        na.proj_w[1] = w->enc[0].W1c; na.proj_b[1] = nullptr;      na.proj_out[1] = PQ1;
+        launch_node(false, na, st);
+    }
+    for (int l = 0; l < 3; ++l) {
+        const codlad_enc_layer &L = w->enc[l];
+        const float *m = mods_t + mods_offset(l);
+        EdgeArgs ea = {};
+        ea.node_info = ni; ea.E_idx = E_idx; ea.n_nodes = n_nodes;
+        ea.hE_in = l == 0 ? h_E0 : ws->hE; ea.in_by_src = l == 0;
+        ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
+        launch_edge(false, ea, st);
+
+        NodeArgs na = {};
+        na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
+        na.W3 = L.W3; na.b3 = L.b3; na.mods = m;
+        for (int c = 0; c < 4; ++c) { na.Win[c] = L.Win[c]; na.Wout[c] = L.Wout[c]; }
+        na.b_in = L.b_in; na.b_out = L.b_out;
+        na.n_proj = 4;
+        na.proj_w[0] = L.W11a; na.proj_b[0] = L.b11;   na.proj_out[0] = PQ2;   // edge update P
+        na.proj_w[1] = L.W11c; na.proj_b[1] = nullptr; na.proj_out[1] = PQ3;   // edge update Q
+        if (l < 2) {
+            na.proj_w[2] = w->enc[l + 1].W1a; na.proj_b[2] = w->enc[l + 1].b1; na.proj_out[2] = PQ0;
+            na.proj_w[3] = w->enc[l + 1].W1c; na.proj_b[3] = nullptr;          na.proj_out[3] = PQ1;
+        } else {
+            // first decoder layer: h_Venc := this h_V, so its neighbour term sees 2*h_V
+            na.proj_w[2] = w->dec[0].W1a; na.proj_b[2] = w->dec[0].b1; na.proj_out[2] = PQ0;
+            na.proj_w[3] = w->dec[0].W1v; na.proj_b[3] = nullptr;      na.proj_out[3] = PQ1;
+            na.proj_flags[3] = 3; na.TS = w->dec[0].TS;
+            na.hVenc_out = ws->hVenc; na.venc_is_self = 1;
+        }
+        launch_node(true, na, st);
+
+        EdgeArgs eu = {};
+        eu.node_info = ni; eu.E_idx = E_idx; eu.n_nodes = n_nodes;
+        eu.hE_in = l == 0 ? h_E0 : ws->hE; eu.in_by_src = l == 0; eu.hE_out = ws->hE;
+        eu.P = PQ2; eu.Q = PQ3; eu.W1 = L.W11e; eu.W2 = L.W12; eu.W3 = L.W13;
+        eu.b2 = L.b12; eu.b3 = L.b13; eu.mods3 = m + 6 * HD;
+        launch_edge(true, eu, st);
+    }
+    for (int l = 0; l < 3; ++l) {
+        const codlad_dec_layer &L = w->dec[l];
+        EdgeArgs ea = {};
+        ea.node_info = ni; ea.E_idx = E_idx; ea.n_nodes = n_nodes;
+        ea.hE_in = ws->hE; ea.in_by_src = 0;
+        ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
+        launch_edge(false, ea, st);
+
+        NodeArgs na = {};
+        na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
+        na.W3 = L.W3; na.b3 = L.b3; na.mods = mods_t + mods_offset(3 + l);
+        for (int c = 0; c < 4; ++c) { na.Win[c] = L.Win[c]; na.Wout[c] = L.Wout[c]; }
+        na.b_in = L.b_in; na.b_out = L.b_out;
+        if (l < 2) {
+            na.n_proj = 2;
+            na.proj_w[0] = w->dec[l + 1].W1a; na.proj_b[0] = w->dec[l + 1].b1; na.proj_out[0] = PQ0;
+            na.proj_w[1] = w->dec[l + 1].W1v; na.proj_b[1] = nullptr;          na.proj_out[1] = PQ1;
+            na.proj_flags[1] = 3; na.TS = w->dec[l + 1].TS; na.hVenc_in = ws->hVenc;
+        }
+        launch_node(true, na, st);
+    }
+}
+
+static int check_ws(const codlad_workspace *ws) {
+    return ws && ws->hV && ws->hVenc && ws->S && ws->PQ && ws->hE;
+}
+
+extern "C" int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t *t_values, int n_t,
+                                float *mods, void *stream) {
+    CODLAD_REQUIRE(w && t_values && mods, "null pointer");
+    CODLAD_REQUIRE(n_t > 0, "n_t must be positive");
+    hipLaunchKernelGGL(mods_kernel, dim3(n_t), dim3(256), 0, (hipStream_t)stream, *w, t_values, mods);
+    return codlad_check_launch("codlad_step_mods");
+}
+
+extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
+                                       int n_nodes, const int32_t *E_idx, const float *h_E0,
+                                       const float *x, const float *mods_t, float *out,
+                                       const codlad_workspace *ws, void *stream) {
+    CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && x && mods_t && out, "null pointer");
+    CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
+    CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, x, mods_t, ws, st);
+    FinalArgs fa = {};
+    fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
+    fa.n_nodes = n_nodes; fa.logits = out;
+    hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
+    return codlad_check_launch("codlad_denoiser_forward");
+}
+
+extern "C" int codlad_ddpm_update(const float *x, const float *model_out, const float *noise,
+                                  const float *coef_host, int n_nodes, float *x_out, void *stream) {
+    CODLAD_REQUIRE(x && model_out && noise && coef_host && x_out, "null pointer");
+    CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
+    const float *c = coef_host;
+    hipLaunchKernelGGL(ddpm_kernel, dim3((n_nodes * 3 + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, x, model_out, noise, c[0], c[1], c[2], c[3], c[4], c[5],
+                       c[6], n_nodes, x_out);
+    return codlad_check_launch("codlad_ddpm_update");
+}
+
+extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_t *node_info,
+                                  int n_nodes, const int32_t *E_idx, const float *h_E0, float *x,
+                                  const float *noise, const float *mods, const float *coef, int T,
+                                  const codlad_workspace *ws, void *stream) {
+    CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && x && noise && mods && coef, "null pointer");
+    CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
+    CODLAD_REQUIRE(n_nodes > 0 && T > 0, "n_nodes and T must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = 0; k < T; ++k) {
+        const int i = T - 1 - k;
+        const float *mods_t = mods + (size_t)i * CODLAD_MODS_PER_STEP;
+        enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, x, mods_t, ws, st);
+        FinalArgs fa = {};
+        fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
+        fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
+        fa.coef = coef + (size_t)i * 8;
+        hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
+    }
+    return codlad_check_launch("codlad_sample_loop");
+}
+
+// ---------------------------------------------------------------------------------------------
+// self-test of the chain primitive
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void selftest_kernel(const float *Wp, const float *bias,
+                                                      const float *X, int n_rows, int act, float *Y) {
+    const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
+    const int row = blockIdx.x * 32 + c;
+    const int rc = row < n_rows ? row : n_rows - 1;
+    Tile in, acc;
+    tile_load_row(in, X + (size_t)rc * HD, h);
+    tile_load_row(acc, bias, h);
+    gemm128(acc, in, Wp, lane);
+    if (act) tile_gelu(acc);
+    if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
+}
+
+extern "C" int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X,
+                                       int n_rows, int act, float *Y, void *stream) {
+    CODLAD_REQUIRE(W_packed && bias && X && Y && n_rows > 0, "bad arguments");
+    hipLaunchKernelGGL(selftest_kernel, dim3((n_rows + 31) / 32), dim3(64), 0, (hipStream_t)stream,
+                       W_packed, bias, X, n_rows, act, Y);
+    return codlad_check_launch("codlad_selftest_gemm128");
+}

@@ -1,0 +1,272 @@
+"""Host-side driver of the HIP sampling path: ragged job tables, workspaces and the calls into
+libcodlad_hip.so.  PyTorch is used for device memory and streams only; every computation on the
+path is a kernel of the library (there is no CPU or eager fallback).
+
+A *structure* is one CA trace (one frame of one protein); a *sample* is one latent trajectory on a
+structure.  Ensemble members of a frame are several samples on the same structure: they share the
+k-NN graph and the initial edge embedding h_E0, which is computed once per structure instead of
+once per denoiser call as the reference does (reference models/latent_model.py:208).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import DenoiserWeights, DecoderWeights
+
+H = 128
+KNN = 64
+MODS = 6016
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on the GPU: this path has no CPU implementation")
+
+
+class Structures:
+    """Flat structure-node arrays + the step-invariant graph/features of every structure."""
+
+    def __init__(self, xyz_list, z_list, device):
+        self.lens = [int(x.shape[0]) for x in xyz_list]
+        assert all(L >= 1 for L in self.lens)
+        self.offsets = np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int64)
+        self.n_snodes = int(self.offsets[-1])
+        self.xyz = torch.cat([x.reshape(-1, 3).float() for x in xyz_list]).contiguous().to(device)
+        self.z = torch.cat([z.reshape(-1).to(torch.int32) for z in z_list]).contiguous().to(device)
+        info = np.empty((self.n_snodes, 2), dtype=np.int32)
+        for f, L in enumerate(self.lens):
+            info[self.offsets[f]:self.offsets[f + 1], 0] = self.offsets[f]
+            info[self.offsets[f]:self.offsets[f + 1], 1] = L
+        self.snode_info = torch.from_numpy(info).to(device)
+        self.E_idx = None
+        self.h_E0 = None
+
+
+class Job:
+    """Samples on structures: node tables + per-step workspace."""
+
+    def __init__(self, structures, sample_struct, device):
+        st = structures
+        self.structures = st
+        self.sample_struct = [int(s) for s in sample_struct]
+        lens = [st.lens[f] for f in self.sample_struct]
+        self.sample_lens = lens
+        self.sample_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        self.n_nodes = int(self.sample_off[-1])
+        info = np.empty((self.n_nodes, 4), dtype=np.int32)
+        z_host = st.z.cpu().numpy()
+        for s, f in enumerate(self.sample_struct):
+            a, b = self.sample_off[s], self.sample_off[s + 1]
+            L = lens[s]
+            info[a:b, 0] = np.arange(st.offsets[f], st.offsets[f] + L)
+            info[a:b, 1] = a
+            info[a:b, 2] = min(KNN, L)
+            info[a:b, 3] = z_host[st.offsets[f]:st.offsets[f] + L]
+        assert info[:, 3].min() >= 0 and info[:, 3].max() < 30, "residue type outside W_s vocabulary"
+        self.node_info = torch.from_numpy(info).to(device)
+        n = self.n_nodes
+        f32 = dict(dtype=torch.float32, device=device)
+        self.hV = torch.empty(n, H, **f32)
+        self.hVenc = torch.empty(n, H, **f32)
+        self.S = torch.empty(n, H, **f32)
+        self.PQ = torch.empty(4, n, H, **f32)
+        self.hE = torch.empty(n, KNN, H, **f32)
+        ws = _lib.Workspace()
+        ws.hV, ws.hVenc, ws.S, ws.PQ, ws.hE = (_lib.ptr(t) for t in (self.hV, self.hVenc, self.S, self.PQ, self.hE))
+        self.ws = ws
+
+    def workspace_bytes(self):
+        return 4 * (self.hV.numel() * 3 + self.PQ.numel() + self.hE.numel())
+
+
+class Denoiser:
+    """mpnn_diffusion on the GPU."""
+
+    def __init__(self, state_dict, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")
+        self.lib = _lib.lib()
+        self.weights = DenoiserWeights(state_dict, self.device)
+        self._mods_cache = {}
+
+    # -- step-invariant part -------------------------------------------------------------------
+    def prepare_structures(self, xyz_list, z_list):
+        st = Structures(xyz_list, z_list, self.device)
+        st.E_idx = torch.empty(st.n_snodes, KNN, dtype=torch.int32, device=self.device)
+        st.h_E0 = torch.empty(st.n_snodes, KNN, H, dtype=torch.float32, device=self.device)
+        rc = self.lib.codlad_features_prepass(C.byref(self.weights.struct), _lib.ptr(st.xyz),
+                                              _lib.ptr(st.snode_info), st.n_snodes, max(st.lens),
+                                              _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
+                                              _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_features_prepass")
+        return st
+
+    def make_job(self, structures, sample_struct):
+        return Job(structures, sample_struct, self.device)
+
+    def step_mods(self, t_values):
+        """[len(t_values), 6016] adaLN modulation vectors; cached per timestep list."""
+        key = tuple(int(t) for t in t_values)
+        if key not in self._mods_cache:
+            tv = torch.tensor(key, dtype=torch.int64, device=self.device)
+            mods = torch.empty(len(key), MODS, dtype=torch.float32, device=self.device)
+            rc = self.lib.codlad_step_mods(C.byref(self.weights.struct), _lib.ptr(tv), len(key),
+                                           _lib.ptr(mods), _lib.stream_ptr(self.device))
+            _lib.check(rc, "codlad_step_mods")
+            if len(self._mods_cache) > 64:
+                self._mods_cache.clear()
+            self._mods_cache[key] = mods
+        return self._mods_cache[key]
+
+    # -- per call ------------------------------------------------------------------------------
+    def forward(self, job, x, t_value):
+        """One denoiser call: x [n_nodes,3] -> [n_nodes,6] (eps | variance logits)."""
+        _require_cuda(x, "x")
+        x = x.contiguous().float()
+        assert x.shape == (job.n_nodes, 3)
+        mods = self.step_mods([t_value])
+        out = torch.empty(job.n_nodes, 6, dtype=torch.float32, device=self.device)
+        st = job.structures
+        rc = self.lib.codlad_denoiser_forward(C.byref(self.weights.struct), _lib.ptr(job.node_info),
+                                              job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
+                                              _lib.ptr(x), _lib.ptr(mods), _lib.ptr(out),
+                                              C.byref(job.ws), _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_denoiser_forward")
+        return out
+
+    def sample(self, job, x_T, noise, tables):
+        """Full ancestral loop.  x_T [n_nodes,3]; noise [T,n_nodes,3] in loop order (first entry
+        is used at step T-1); tables = diffusion_and_flow.schedule.Tables.  Returns x_0."""
+        _require_cuda(x_T, "x_T")
+        _require_cuda(noise, "noise")
+        T = tables.num_timesteps
+        assert noise.shape == (T, job.n_nodes, 3) and x_T.shape == (job.n_nodes, 3)
+        x = x_T.detach().clone().contiguous().float()
+        noise = noise.contiguous().float()
+        mods = self.step_mods(tables.timestep_map)
+        coef = torch.from_numpy(tables.step_coefficients()).to(self.device)
+        st = job.structures
+        rc = self.lib.codlad_sample_loop(C.byref(self.weights.struct), _lib.ptr(job.node_info),
+                                         job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
+                                         _lib.ptr(x), _lib.ptr(noise), _lib.ptr(mods), _lib.ptr(coef),
+                                         T, C.byref(job.ws), _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_sample_loop")
+        return x
+
+    def ddpm_update(self, x, model_out, noise, tables, i):
+        _require_cuda(x, "x")
+        n = x.numel() // 3
+        x = x.contiguous().float()
+        out = torch.empty_like(x)
+        coef = np.ascontiguousarray(tables.step_coefficients()[i])
+        rc = self.lib.codlad_ddpm_update(_lib.ptr(x), _lib.ptr(model_out.contiguous().float()),
+                                         _lib.ptr(noise.contiguous().float()),
+                                         coef.ctypes.data_as(C.c_void_p), n, _lib.ptr(out),
+                                         _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_ddpm_update")
+        return out
+
+
+class Decoder:
+    """De-normalise + VQ lookup + IC decoder + ic_to_xyz."""
+
+    def __init__(self, state_dict, device, mean3=None, std3=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")
+        self.lib = _lib.lib()
+        self.weights = DecoderWeights(state_dict, self.device)
+        f = dict(dtype=torch.float32, device=self.device)
+        self.mean = (torch.zeros(3) if mean3 is None else mean3).to(**f).contiguous()
+        self.std = (torch.ones(3) if std3 is None else std3).to(**f).contiguous()
+        self._unit = (torch.zeros(3, **f), torch.ones(3, **f))
+
+    def vq(self, x, normalised=True):
+        """x [..., 3] -> (idx int64 [n], z_q [..., 3], latent [..., 3]); de-normalises first when
+        `normalised` (reference test.py:548), else looks x up as is."""
+        _require_cuda(x, "latent")
+        xs = x.contiguous().float()
+        n = xs.numel() // 3
+        idx = torch.empty(n, dtype=torch.int64, device=self.device)
+        zq = torch.empty_like(xs)
+        lat = torch.empty_like(xs)
+        mean, std = (self.mean, self.std) if normalised else self._unit
+        cb = self.weights.codebook
+        rc = self.lib.codlad_vq_lookup(_lib.ptr(xs), n, _lib.ptr(mean), _lib.ptr(std), _lib.ptr(cb),
+                                       cb.shape[0], _lib.ptr(idx), _lib.ptr(zq), _lib.ptr(lat),
+                                       _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_vq_lookup")
+        return idx, zq, lat
+
+    @staticmethod
+    def csr_from_pairs(pairs, n_nodes):
+        """Undirected CG pairs [E,2] -> CSR over the receiving node of the directed graph, in the
+        order the reference's scatter_add visits them (models/gcn_nn.py:54-64, vae_model.py:485)."""
+        gtr_ij = bool((pairs[:, 0] > pairs[:, 1]).any())
+        gtr_ji = bool((pairs[:, 1] > pairs[:, 0]).any())
+        directed = pairs if (gtr_ij and gtr_ji) else torch.cat([pairs, pairs.flip(1)], dim=0)
+        recv = directed[:, 0]
+        order = torch.sort(recv, stable=True).indices
+        src = directed[order, 1].to(torch.int32).contiguous()
+        counts = torch.bincount(recv, minlength=n_nodes)
+        ptr = torch.zeros(n_nodes + 1, dtype=torch.int32, device=pairs.device)
+        ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return ptr, src
+
+    def ic_decode(self, z_q, cg_z, cg_xyz, pairs):
+        """z_q [M,3], cg_z [M], cg_xyz [M,3], pairs [E,2] (flat node indices) -> ic [M,13,3]."""
+        _require_cuda(z_q, "z_q")
+        M = z_q.shape[0]
+        ptr, src = self.csr_from_pairs(pairs.to(self.device), M)
+        scratch = torch.empty(M, 200, dtype=torch.float32, device=self.device)
+        ic = torch.empty(M, 13, 3, dtype=torch.float32, device=self.device)
+        rc = self.lib.codlad_ic_decode(C.byref(self.weights.struct), _lib.ptr(z_q.contiguous().float()),
+                                       _lib.ptr(cg_z.to(self.device, torch.int32).contiguous()),
+                                       _lib.ptr(cg_xyz.to(self.device).contiguous().float()),
+                                       _lib.ptr(ptr), _lib.ptr(src), M, _lib.ptr(scratch), _lib.ptr(ic),
+                                       _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_ic_decode")
+        return ic
+
+    def ic_to_xyz(self, ca_full, ic, info):
+        """ca_full [B,L+2,3], ic [B,L,13,3], info = (permute, atom_idx, atom_orders) -> [B,n_atoms,3]."""
+        _require_cuda(ic, "ic")
+        B, L = ic.shape[0], ic.shape[1]
+        orders, slot_to_out, n_atoms = info_tables(info, L, self.device)
+        out = torch.empty(B, n_atoms, 3, dtype=torch.float32, device=self.device)
+        rc = self.lib.codlad_ic_to_xyz(_lib.ptr(ca_full.to(self.device).contiguous().float()),
+                                       _lib.ptr(ic.contiguous().float()), _lib.ptr(orders),
+                                       _lib.ptr(slot_to_out), B, L, n_atoms, _lib.ptr(out),
+                                       _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_ic_to_xyz")
+        return out
+
+
+_INFO_CACHE = {}
+
+
+def info_tables(info, L, device):
+    """(permute, atom_idx, atom_orders) of the reference (utils/protein_module.py:434-494) ->
+    int32 device tables for codlad_ic_to_xyz.  Output atom p takes slot atom_idx[permute[p]]
+    (utils/utils_ic.py:267)."""
+    permute, atom_idx, orders = info
+    key = (id(permute), id(atom_idx), id(orders), L, str(device))
+    if key not in _INFO_CACHE:
+        assert orders.shape == (10, L, 3), "atom_orders does not match the batch's residue count"
+        n_atoms = int(permute.numel())
+        slot = atom_idx.cpu()[permute.cpu()]
+        assert int(slot.max()) < 14 * L and torch.unique(slot).numel() == n_atoms
+        s2o = torch.full((14 * L,), -1, dtype=torch.int32)
+        s2o[slot] = torch.arange(n_atoms, dtype=torch.int32)
+        o32 = orders.to(torch.int32).contiguous()
+        assert int(o32.min()) >= 0
+        for i in range(10):  # slot i+4 may only reference earlier slots
+            assert int(o32[i].max()) < 4 + i, "atom_orders references an atom that is not placed yet"
+        if len(_INFO_CACHE) > 256:
+            _INFO_CACHE.clear()
+        _INFO_CACHE[key] = (o32.to(device), s2o.to(device), n_atoms, info)
+    o, s, n, _keepalive = _INFO_CACHE[key]
+    return o, s, n

@@ -1,0 +1,226 @@
+"""Checkpoint tensors -> one device blob + the pointer structs of include/codlad_hip.h.
+
+Inputs are state_dicts with the reference's key layout:
+  denoiser: models/latent_model.py:119-148 (108 tensors), optional `module.` prefix;
+  VQ-VAE  : utils/model_module.py:39-75 -> equivaraintconv.*, map_out.*, quantize.*.
+
+The blob layout depends on tensor shapes only, so every rank of a multi-GPU job derives the
+same offsets and rank 0 can broadcast the blob as one buffer over RCCL.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+H = 128
+_ALIGN = 64  # floats (256 bytes)
+
+
+def _pack_index():
+    """Row/col of the source 128x128 block for every element of the MFMA-operand order
+    (must equal codlad_pack_block_host)."""
+    b, r, lane, bo = np.meshgrid(np.arange(4), np.arange(16), np.arange(64), np.arange(4), indexing="ij")
+    rows = 32 * bo + (lane & 31)
+    cols = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    return torch.from_numpy(rows.reshape(-1)), torch.from_numpy(cols.reshape(-1))
+
+
+_ROWS, _COLS = _pack_index()
+
+
+def pack_block(w, scale=1.0):
+    """[128,128] weight block (out, in) -> 16384 floats in MFMA A-operand order."""
+    assert tuple(w.shape) == (H, H)
+    out = w.detach().float().cpu()[_ROWS, _COLS]
+    return out * scale if scale != 1.0 else out.clone()
+
+
+def strip_module_prefix(sd):
+    """Checkpoints saved from a DDP-wrapped model carry `module.` (reference test.py:279-286)."""
+    if all(k.startswith("module.") for k in sd):
+        return OrderedDict((k[7:], v) for k, v in sd.items())
+    return sd
+
+
+def denoiser_tensors(sd):
+    """Ordered name -> host fp32 tensor, as laid out in the blob."""
+    sd = strip_module_prefix(sd)
+    g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
+    t = OrderedDict()
+    # latent_model.py:62-64 and protein_mpnn_utils.py:464-465, evaluated the way the reference does
+    t["freqs"] = torch.exp(-math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128)
+    t["rbf_mu"] = torch.linspace(2.0, 22.0, 16)
+    t["t_w0"], t["t_b0"] = g("t_embedder.mlp.0.weight"), g("t_embedder.mlp.0.bias")
+    t["t_w2"], t["t_b2"] = g("t_embedder.mlp.2.weight"), g("t_embedder.mlp.2.bias")
+    heads = [f"encoder_layers.{l}" for l in range(3)] + [f"decoder_layers.{l}" for l in range(3)] + ["W_out"]
+    for i, hname in enumerate(heads):
+        t[f"ada_w{i}"] = g(f"{hname}.adaLN_modulation.1.weight")
+        t[f"ada_b{i}"] = g(f"{hname}.adaLN_modulation.1.bias")
+    t["x_in_w"], t["x_in_b"] = g("x_in.weight"), g("x_in.bias")
+    assert t["x_in_w"].shape == (H, 3), "only latent_size 3 (N6/K3/K4) is built"
+    t["pos_w"], t["pos_b"] = g("features.embeddings.linear.weight"), g("features.embeddings.linear.bias")
+    t["edge_wT"] = g("features.edge_embedding.weight").t().contiguous()
+    t["norm_w"], t["norm_b"] = g("features.norm_edges.weight"), g("features.norm_edges.bias")
+    t["We_wT"], t["We_b"] = g("W_e.weight").t().contiguous(), g("W_e.bias")
+    t["out_w"], t["out_b"] = g("W_out.linear.weight"), g("W_out.linear.bias")
+    assert t["out_w"].shape == (6, H)
+    for l in range(3):
+        p = f"encoder_layers.{l}"
+        W1, W11 = g(f"{p}.W1.weight"), g(f"{p}.W11.weight")
+        e = f"enc{l}."
+        t[e + "W1e"] = pack_block(W1[:, 128:256]); t[e + "W2"] = pack_block(g(f"{p}.W2.weight"))
+        t[e + "W3"] = pack_block(g(f"{p}.W3.weight"))
+        t[e + "W11e"] = pack_block(W11[:, 128:256]); t[e + "W12"] = pack_block(g(f"{p}.W12.weight"))
+        t[e + "W13"] = pack_block(g(f"{p}.W13.weight"))
+        t[e + "W1a"] = pack_block(W1[:, 0:128]); t[e + "W1c"] = pack_block(W1[:, 256:384])
+        t[e + "W11a"] = pack_block(W11[:, 0:128]); t[e + "W11c"] = pack_block(W11[:, 256:384])
+        Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
+        for c in range(4):
+            t[e + f"Win{c}"] = pack_block(Win[128 * c:128 * c + 128, :])
+            t[e + f"Wout{c}"] = pack_block(Wout[:, 128 * c:128 * c + 128])
+        for b, k in (("b1", "W1"), ("b2", "W2"), ("b3", "W3"), ("b11", "W11"), ("b12", "W12"), ("b13", "W13")):
+            t[e + b] = g(f"{p}.{k}.bias")
+        t[e + "b_in"], t[e + "b_out"] = g(f"{p}.dense.W_in.bias"), g(f"{p}.dense.W_out.bias")
+    Ws = g("W_s.weight")
+    for l in range(3):
+        p = f"decoder_layers.{l}"
+        W1 = g(f"{p}.W1.weight")
+        d = f"dec{l}."
+        # h_ESV = [h_E|h_S_j|h_V_j] + [h_E|h_S_j|h_Venc_j] (latent_model.py:260-261): h_E and h_S doubled
+        t[d + "W1e"] = pack_block(W1[:, 128:256], 2.0)
+        t[d + "W2"] = pack_block(g(f"{p}.W2.weight")); t[d + "W3"] = pack_block(g(f"{p}.W3.weight"))
+        t[d + "W1a"] = pack_block(W1[:, 0:128]); t[d + "W1v"] = pack_block(W1[:, 384:512])
+        t[d + "TS"] = F.linear(2.0 * Ws, W1[:, 256:384]).contiguous()  # [30,128]
+        Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
+        for c in range(4):
+            t[d + f"Win{c}"] = pack_block(Win[128 * c:128 * c + 128, :])
+            t[d + f"Wout{c}"] = pack_block(Wout[:, 128 * c:128 * c + 128])
+        for b, k in (("b1", "W1"), ("b2", "W2"), ("b3", "W3")):
+            t[d + b] = g(f"{p}.{k}.bias")
+        t[d + "b_in"], t[d + "b_out"] = g(f"{p}.dense.W_in.bias"), g(f"{p}.dense.W_out.bias")
+    return t
+
+
+def decoder_tensors(sd):
+    """IC decoder + map_out + codebook (reference models/vae_model.py:318-503, 704-706)."""
+    g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
+    p = "equivaraintconv."
+    angle = (p + "sidechain_angle.1.weight") in sd
+    t = OrderedDict()
+    t["map_out_w"], t["map_out_b"] = g("map_out.weight"), g("map_out.bias")
+    t["res_embed"] = g(p + "res_embed.weight")
+    for i in range(4):
+        m = f"{p}message_blocks.{i}."
+        t[f"inv0_w{i}"], t[f"inv0_b{i}"] = g(m + "inv_dense.0.weight"), g(m + "inv_dense.0.bias")
+        t[f"inv1_w{i}"], t[f"inv1_b{i}"] = g(m + "inv_dense.1.weight"), g(m + "inv_dense.1.bias")
+        t[f"dist_w{i}"], t[f"dist_b{i}"] = g(m + "dist_embed.block.1.weight"), g(m + "dist_embed.block.1.bias")
+        d = f"{p}dense_blocks.{i}."
+        t[f"dense1_w{i}"], t[f"dense1_b{i}"] = g(d + "1.weight"), g(d + "1.bias")
+        t[f"dense3_w{i}"], t[f"dense3_b{i}"] = g(d + "3.weight"), g(d + "3.bias")
+        s = f"{p}sidechain_torsion_blocks.{i}."
+        t[f"tor1_w{i}"], t[f"tor1_b{i}"] = g(s + "1.weight"), g(s + "1.bias")
+        t[f"tor3_w{i}"], t[f"tor3_b{i}"] = g(s + "3.weight"), g(s + "3.bias")
+    t["bb_dist"], t["sc_dist"] = g(p + "backbone_dist.weight"), g(p + "sidechain_dist.weight")
+    for nm, key in (("bb_ang", "backbone_angle"), ("bb_tor", "backbone_torsion"), ("fin", "final_torsion")):
+        t[nm + "1_w"], t[nm + "1_b"] = g(f"{p}{key}.1.weight"), g(f"{p}{key}.1.bias")
+        t[nm + "3_w"], t[nm + "3_b"] = g(f"{p}{key}.3.weight"), g(f"{p}{key}.3.bias")
+    if angle:
+        t["sc_ang1_w"], t["sc_ang1_b"] = g(p + "sidechain_angle.1.weight"), g(p + "sidechain_angle.1.bias")
+        t["sc_ang3_w"], t["sc_ang3_b"] = g(p + "sidechain_angle.3.weight"), g(p + "sidechain_angle.3.bias")
+    else:
+        t["sc_angle_emb"] = g(p + "sidechain_angle.weight")
+    if "quantize._codebook.embed" in sd:          # vector_quantize_pytorch EuclideanCodebook
+        t["codebook"] = g("quantize._codebook.embed")[0].contiguous()
+    elif "quantize.embeddings" in sd:             # in-repo VectorQuantizerEMA (utils/vq_module.py:52)
+        t["codebook"] = g("quantize.embeddings")
+    return t, angle
+
+
+class Blob:
+    """name -> fp32 tensor, stored back to back (256-byte aligned) in one device buffer."""
+
+    def __init__(self, tensors, device):
+        self.offsets = OrderedDict()
+        off = 0
+        for k, v in tensors.items():
+            self.offsets[k] = (off, tuple(v.shape))
+            off += (v.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        host = torch.zeros(off, dtype=torch.float32)
+        for k, v in tensors.items():
+            o, _ = self.offsets[k]
+            host[o:o + v.numel()] = v.reshape(-1)
+        self.data = host.to(device)
+
+    def ptr(self, name):
+        if name not in self.offsets:
+            return None
+        return C.c_void_p(self.data.data_ptr() + 4 * self.offsets[name][0])
+
+    def view(self, name):
+        o, shape = self.offsets[name]
+        n = int(np.prod(shape))
+        return self.data[o:o + n].view(shape)
+
+
+class DenoiserWeights:
+    def __init__(self, state_dict, device):
+        self.blob = Blob(denoiser_tensors(state_dict), device)
+        self.struct = self._fill()
+
+    def _fill(self):
+        w = _lib.DenoiserWeights()
+        p = self.blob.ptr
+        for n in ("freqs", "rbf_mu", "t_w0", "t_b0", "t_w2", "t_b2", "x_in_w", "x_in_b", "pos_w", "pos_b",
+                  "edge_wT", "norm_w", "norm_b", "We_wT", "We_b", "out_w", "out_b"):
+            setattr(w, n, p(n))
+        for i in range(7):
+            w.ada_w[i], w.ada_b[i] = p(f"ada_w{i}"), p(f"ada_b{i}")
+        for l in range(3):
+            e, d = w.enc[l], w.dec[l]
+            for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c",
+                      "b1", "b2", "b3", "b11", "b12", "b13", "b_in", "b_out"):
+                setattr(e, n, p(f"enc{l}.{n}"))
+            for n in ("W1e", "W2", "W3", "W1a", "W1v", "TS", "b1", "b2", "b3", "b_in", "b_out"):
+                setattr(d, n, p(f"dec{l}.{n}"))
+            for c in range(4):
+                e.Win[c], e.Wout[c] = p(f"enc{l}.Win{c}"), p(f"enc{l}.Wout{c}")
+                d.Win[c], d.Wout[c] = p(f"dec{l}.Win{c}"), p(f"dec{l}.Wout{c}")
+        return w
+
+    def rebind(self):
+        """Re-derive the pointers after the blob storage changed (e.g. after a broadcast)."""
+        self.struct = self._fill()
+
+
+class DecoderWeights:
+    def __init__(self, state_dict, device):
+        tensors, self.angle = decoder_tensors(state_dict)
+        self.blob = Blob(tensors, device)
+        self.struct = self._fill()
+
+    def _fill(self):
+        w = _lib.DecoderWeights()
+        p = self.blob.ptr
+        w.angle = int(self.angle)
+        for n in ("map_out_w", "map_out_b", "res_embed", "bb_dist", "sc_dist", "bb_ang1_w", "bb_ang1_b",
+                  "bb_ang3_w", "bb_ang3_b", "sc_angle_emb", "sc_ang1_w", "sc_ang1_b", "sc_ang3_w",
+                  "sc_ang3_b", "bb_tor1_w", "bb_tor1_b", "bb_tor3_w", "bb_tor3_b", "fin1_w", "fin1_b",
+                  "fin3_w", "fin3_b"):
+            setattr(w, n, p(n))
+        for i in range(4):
+            for n in ("inv0_w", "inv0_b", "inv1_w", "inv1_b", "dist_w", "dist_b", "dense1_w", "dense1_b",
+                      "dense3_w", "dense3_b", "tor1_w", "tor1_b", "tor3_w", "tor3_b"):
+                getattr(w, n)[i] = p(f"{n}{i}")
+        return w
+
+    def rebind(self):
+        self.struct = self._fill()
+
+    @property
+    def codebook(self):
+        return self.blob.view("codebook")

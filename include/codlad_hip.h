@@ -1,0 +1,180 @@
+/*
+ * libcodlad_hip.so - C ABI of the MI355X (gfx950) sampling hot path of CODLAD.
+ *
+ * The reference (pure PyTorch) has no FFI layer; its boundary for this path is a set of
+ * Python call signatures.  Each entry point below names the reference
+ * code it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - fp32 row-major, indices int32 unless stated, VQ indices int64;
+ *   - the caller owns every buffer (inputs, outputs, workspace); nothing is allocated here;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work;
+ *   - return 0 = ok, < 0 = argument error, > 0 = hipError_t; codlad_last_error() has text;
+ *   - not thread-safe per handle; one process per GPU.
+ *
+ * Ragged layout ("job")
+ *   A job is S samples, sample s has L_s residues ("nodes").  Node arrays are flat,
+ *   sample-major: n_nodes = sum L_s.  Several samples may share one structure
+ *   (ensemble members of one frame): structure arrays are flat over structure nodes
+ *   (n_snodes = sum over structures of L_f).  No padding anywhere, so there are no masks.
+ *   node_info[n] = {src, base, K, z}:
+ *       src  = flat structure-node index of node n (row of E_idx / h_E0 / cg_z),
+ *       base = flat index of the first node of n's sample,
+ *       K    = min(64, L_s) neighbours, z = residue type (0..29).
+ *   E_idx[src][k], k < K, is the neighbour's index inside its own structure (0..L-1).
+ */
+#ifndef CODLAD_HIP_H
+#define CODLAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODLAD_ABI_VERSION 1
+#define CODLAD_H 128          /* hidden width of the denoiser                          */
+#define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
+#define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
+#define CODLAD_PACKED_BLOCK 16384 /* floats of one 128x128 block in MFMA operand order  */
+
+int codlad_abi_version(void);
+const char *codlad_last_error(void);
+
+/* 128x128 weight block -> MFMA A-operand order (host helper; src/dst are HOST pointers).
+ * dst[(16*b + r)*256 + lane*4 + bo] = src[(32*bo + (lane&31))*ld + 32*b + (r&3) + 8*(r>>2) + 4*(lane>>5)]
+ * scaled by `scale`. */
+void codlad_pack_block_host(const float *src_host, int ld, float scale, float *dst_host);
+
+/* Encoder layer weights.  W* are packed 128x128 blocks (codlad_pack_block_host), b* plain. */
+typedef struct {
+    const float *W1e, *W2, *W3;        /* message MLP: W1[:,128:256], W2, W3                 */
+    const float *W11e, *W12, *W13;     /* edge-update MLP: W11[:,128:256], W12, W13           */
+    const float *W1a, *W1c;            /* W1[:,0:128] (own node), W1[:,256:384] (neighbour)   */
+    const float *W11a, *W11c;
+    const float *Win[4], *Wout[4];     /* dense.W_in rows 128c.., dense.W_out cols 128c..     */
+    const float *b1, *b2, *b3, *b11, *b12, *b13, *b_in /*512*/, *b_out;
+} codlad_enc_layer;
+
+typedef struct {
+    const float *W1e;                  /* 2 * W1[:,128:256]  (h_ESV doubles h_E)              */
+    const float *W2, *W3;
+    const float *W1a;                  /* W1[:,0:128]                                          */
+    const float *W1v;                  /* W1[:,384:512]  applied to h_V_j + h_Venc_j           */
+    const float *TS;                   /* [30][128]: W1[:,256:384] @ (2*W_s[z])                */
+    const float *Win[4], *Wout[4];
+    const float *b1, *b2, *b3, *b_in, *b_out;
+} codlad_dec_layer;
+
+/* Replaces the parameters of reference models/latent_model.py:119-148 (ProteinMPNN_diffusion_new). */
+typedef struct {
+    const float *freqs;                /* [128] exp(-ln(1e4) k/128)  (latent_model.py:62-64)   */
+    const float *rbf_mu;               /* [16] linspace(2, 22, 16)  (protein_mpnn_utils.py:464-465) */
+    const float *t_w0, *t_b0;          /* t_embedder.mlp.0  [128][256], [128]                  */
+    const float *t_w2, *t_b2;          /* t_embedder.mlp.2  [128][128], [128]                  */
+    const float *ada_w[7], *ada_b[7];  /* adaLN heads: enc0..2 [1152][128], dec0..2 [768][128], final [256][128] */
+    const float *x_in_w, *x_in_b;      /* [128][3], [128]                                      */
+    const float *pos_w, *pos_b;        /* features.embeddings.linear [16][66], [16]            */
+    const float *edge_wT;              /* features.edge_embedding.weight TRANSPOSED [167][128] */
+    const float *norm_w, *norm_b;      /* features.norm_edges                                   */
+    const float *We_wT, *We_b;         /* W_e.weight TRANSPOSED [128][128], [128]              */
+    const float *out_w, *out_b;        /* W_out.linear [6][128], [6]                           */
+    codlad_enc_layer enc[3];
+    codlad_dec_layer dec[3];
+} codlad_denoiser_weights;
+
+/* Row 4: CA_ProteinFeatures.forward + W_e
+ * (reference models/protein_mpnn_utils.py:478-523, latent_model.py:208,216).
+ * snode_info[m] = {start, L} of the structure that structure-node m belongs to.
+ * Writes E_idx [n_snodes][64] (ascending distance, self first) and h_E0 [n_snodes][64][128]. */
+int codlad_features_prepass(const codlad_denoiser_weights *w, const float *cg_xyz,
+                            const int32_t *snode_info, int n_snodes, int max_len,
+                            int32_t *E_idx, float *h_E0, void *stream);
+
+/* Row 3: TimestepEmbedder + every adaLN head for n_t timesteps
+ * (latent_model.py:37-75; protein_mpnn_utils.py:238,298; latent_model.py:32).
+ * t_values: DEVICE int64 [n_t] (already mapped through timestep_map).  mods [n_t][6016]. */
+int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t *t_values, int n_t,
+                     float *mods, void *stream);
+
+/* Workspace of one job, all caller-allocated. */
+typedef struct {
+    float *hV;      /* [n_nodes][128]                 */
+    float *hVenc;   /* [n_nodes][128]                 */
+    float *S;       /* [n_nodes][128]                 */
+    float *PQ;      /* [4][n_nodes][128]              */
+    float *hE;      /* [n_nodes][64][128]             */
+} codlad_workspace;
+
+/* Rows 5-7: one denoiser forward (latent_model.py:175-268): x [n_nodes][3] -> out [n_nodes][6].
+ * mods_t = the 6016 modulation floats of this timestep. */
+int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
+                            int n_nodes, const int32_t *E_idx, const float *h_E0,
+                            const float *x, const float *mods_t, float *out,
+                            const codlad_workspace *ws, void *stream);
+
+/* Row 2: one reverse step given the model output (gaussian_diffusion.py:404-449, 262-360).
+ * coef_host[8] = {sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2,
+ *                 post_log_var_clipped, log_beta, nonzero(0/1), 0} for this step. */
+int codlad_ddpm_update(const float *x, const float *model_out, const float *noise,
+                       const float *coef_host, int n_nodes, float *x_out, void *stream);
+
+/* Rows 2-7 fused: p_sample_loop (gaussian_diffusion.py:451-547, respace.py:124-129).
+ * x [n_nodes][3] holds x_T on entry and x_0 on return.  noise [T][n_nodes][3] is consumed in
+ * loop order (entry 0 at step T-1).  mods [T][6016] and coef [T][8] (device) are indexed by
+ * respaced step i; the loop runs i = T-1 .. 0. */
+int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_t *node_info, int n_nodes,
+                       const int32_t *E_idx, const float *h_E0, float *x, const float *noise,
+                       const float *mods, const float *coef, int T,
+                       const codlad_workspace *ws, void *stream);
+
+/* Row 8: get_norm_feature(norm_in=False) + nearest code
+ * (utils/dataset_module.py:253; utils/vq_module.py:61-68 / VectorQuantize eval lookup).
+ * x [n][3] normalised samples -> latent = x*std+mean; idx int64 [n]; z_q [n][3]. */
+int codlad_vq_lookup(const float *x, int n, const float *mean3, const float *std3,
+                     const float *codebook, int n_codes, int64_t *idx, float *z_q,
+                     float *latent_out /* may be NULL */, void *stream);
+
+/* IC decoder weights (reference models/vae_model.py:318-373, 414-465), plain row-major. */
+typedef struct {
+    int angle;                          /* 0 = IC_Decoder (N6), 1 = IC_Decoder_angle (K3/K4)  */
+    const float *map_out_w, *map_out_b; /* [36][3], [36]                                       */
+    const float *res_embed;             /* [25][4]                                             */
+    const float *inv0_w[4], *inv0_b[4], *inv1_w[4], *inv1_b[4];   /* [40][40]                  */
+    const float *dist_w[4], *dist_b[4];                           /* [40][15]                  */
+    const float *dense1_w[4], *dense1_b[4], *dense3_w[4], *dense3_b[4];
+    const float *bb_dist, *sc_dist;     /* [25][3], [25][10]                                   */
+    const float *bb_ang1_w, *bb_ang1_b, *bb_ang3_w, *bb_ang3_b;   /* [3][40], [3][3]           */
+    const float *sc_angle_emb;          /* [25][10]   (angle == 0)                             */
+    const float *sc_ang1_w, *sc_ang1_b, *sc_ang3_w, *sc_ang3_b;   /* [10][40], [10][10] (angle == 1) */
+    const float *bb_tor1_w, *bb_tor1_b, *bb_tor3_w, *bb_tor3_b;   /* [3][43], [3][3]           */
+    const float *tor1_w[4], *tor1_b[4], *tor3_w[4], *tor3_b[4];   /* [F][F], F = 40 or 50      */
+    const float *fin1_w, *fin1_b, *fin3_w, *fin3_b;               /* [10][F], [10][10]         */
+} codlad_decoder_weights;
+
+/* Row 9: VAE.decoder = map_out + IC_Decoder[_angle].forward (vae_model.py:759-764, 375-412, 467-503).
+ * z_q [M][3], cg_z int32 [M], cg_xyz [M][3]; directed CG graph in CSR over receiving node:
+ * csr_ptr int32 [M+1], csr_src int32 [E_dir] (sending node of each incoming edge, flat index).
+ * scratch: float [M][200].  ic_out [M][13][3]. */
+int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_q, const int32_t *cg_z,
+                     const float *cg_xyz, const int32_t *csr_ptr, const int32_t *csr_src,
+                     int M, float *scratch, float *ic_out, void *stream);
+
+/* Row 10: ic_to_xyz (utils/utils_ic.py:242-268).  ca_full [B][L+2][3] (flanking residues
+ * included), ic [B][L][13][3], orders int32 [10][L][3] (atom_orders), slot_to_out int32 [L*14]
+ * (output atom index of each residue slot, -1 = slot unused; derived from info's
+ * atom_idx/permute).  xyz_out [B][n_atoms][3]. */
+int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *orders,
+                     const int32_t *slot_to_out, int B, int L, int n_atoms, float *xyz_out,
+                     void *stream);
+
+/* Self-test of the MFMA chain primitive: Y[n][:] = act(W @ X[n][:] + bias), n < 32*tiles.
+ * act: 0 = none, 1 = exact-erf GELU. */
+int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X, int n_rows,
+                            int act, float *Y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

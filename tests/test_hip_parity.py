@@ -1,0 +1,270 @@
+"""GPU parity: every HIP entry point of libcodlad_hip.so against the CPU oracle (and the
+reference-generated goldens) on the same seeded inputs.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from codlad_amd import _lib, synth
+from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
+from codlad_amd.engine import Decoder, Denoiser
+from codlad_amd.weights import pack_block
+from oracle import denoiser as oden
+from oracle import sampler as osam
+from oracle import vae_decode as odec
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth.denoiser_state_dict(cases.WEIGHT_SEED)
+
+
+@pytest.fixture(scope="module")
+def den(sd):
+    return Denoiser(sd, DEV)
+
+
+def tables(T):
+    return Tables(named_betas("linear", 1000), space_timesteps(1000, str(T)))
+
+
+def structures_of(den, prot):
+    frames = torch.from_numpy(prot["xyz_full"])[:, 1:-1]
+    z = torch.from_numpy(prot["z_full"])[1:-1]
+    return den.prepare_structures([f for f in frames], [z for _ in frames])
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", [0, 1])
+def test_mfma_chain_primitive(act):
+    """Packing order + C-layout chain: Y = act(W X + b) against fp64."""
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(128, 128, generator=g) / 11.0
+    W[3, 7] = 2.5  # asymmetric marker
+    b = torch.randn(128, generator=g)
+    X = torch.randn(77, 128, generator=g)  # ragged tail: 77 = 2*32 + 13
+    Y = torch.empty(77, 128, device=DEV)
+    rc = _lib.lib().codlad_selftest_gemm128(_lib.ptr(pack_block(W).to(DEV)), _lib.ptr(b.to(DEV)),
+                                            _lib.ptr(X.to(DEV)), 77, act, _lib.ptr(Y), None)
+    _lib.check(rc, "selftest")
+    torch.cuda.synchronize()
+    ref = X.double() @ W.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    assert rel_err(Y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("name", list(cases.DENOISER_CASES))
+def test_features_prepass(den, sd, name):
+    L, B, seed = cases.DENOISER_CASES[name]
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    st = structures_of(den, prot)
+    torch.cuda.synchronize()
+    cg_z, cg_xyz, m = oden.batch_to_dense(batch)
+    E, E_idx = oden.ca_features(sd, cg_xyz, m.int())
+    hE0 = torch.nn.functional.linear(E, sd["W_e.weight"], sd["W_e.bias"])
+    K = min(64, L)
+    got_idx = st.E_idx.cpu().view(B, L, 64)[:, :, :K].long()
+    assert torch.equal(got_idx, E_idx)                      # neighbour lists: exact
+    gold = np.load(cases.npz_path(f"g2_forward_{name}"))
+    assert torch.equal(got_idx, torch.from_numpy(gold["E_idx"]))
+    got = st.h_E0.cpu().view(B, L, 64, 128)[:, :, :K]
+    assert rel_err(got, hE0) < 5e-6
+
+
+def test_step_mods(den, sd):
+    tv = [999, 500, 10, 0]
+    mods = den.step_mods(tv).cpu()
+    c = oden.t_embed(sd, torch.tensor(tv))
+    sc = torch.nn.functional.silu(c)
+    heads = [f"encoder_layers.{l}" for l in range(3)] + [f"decoder_layers.{l}" for l in range(3)] + ["W_out"]
+    ref = torch.cat([torch.nn.functional.linear(sc, sd[f"{h}.adaLN_modulation.1.weight"],
+                                                sd[f"{h}.adaLN_modulation.1.bias"]) for h in heads], dim=1)
+    assert ref.shape == mods.shape
+    assert rel_err(mods, ref) < 5e-6
+
+
+@pytest.mark.parametrize("name", list(cases.DENOISER_CASES))
+def test_denoiser_forward(den, sd, name):
+    L, B, seed = cases.DENOISER_CASES[name]
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    st = structures_of(den, prot)
+    job = den.make_job(st, list(range(B)))
+    out = den.forward(job, x.reshape(-1, 3).to(DEV), int(t[0])).cpu().view(B, L, 6)
+    cg_z, cg_xyz, m = oden.batch_to_dense(batch)
+    ref = oden.forward(sd, x, t, cg_xyz, cg_z, mask)
+    assert rel_err(out, ref) < 1e-5
+    gold = np.load(cases.npz_path(f"g2_forward_{name}"))
+    assert rel_err(out, gold["out"]) < 1e-5
+    if "enc0_hV" in gold.files:  # intermediate left in the workspace: last decoder h_V
+        assert rel_err(job.hV.cpu().view(B, L, 128), gold["dec2_hV"]) < 1e-5
+
+
+def test_ensemble_members_share_structure(den, sd):
+    """Two samples on ONE structure == the same two samples on two copies of it."""
+    L, B, seed = cases.DENOISER_CASES["L46_B2"]
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    frames = torch.from_numpy(prot["xyz_full"])[:, 1:-1]
+    z = torch.from_numpy(prot["z_full"])[1:-1]
+    st1 = den.prepare_structures([frames[0]], [z])
+    st2 = den.prepare_structures([frames[0], frames[0]], [z, z])
+    xx = x.reshape(-1, 3).to(DEV)
+    o1 = den.forward(den.make_job(st1, [0, 0]), xx, 321)
+    o2 = den.forward(den.make_job(st2, [0, 1]), xx, 321)
+    assert torch.equal(o1, o2)
+
+
+def test_ragged_job_matches_separate_jobs(den, sd):
+    """Mixed lengths in one launch (no padding) == each length on its own."""
+    pa = synth.make_protein(46, 12, n_frames=1)
+    pb = synth.make_protein(87, 13, n_frames=1)
+    za, zb = torch.from_numpy(pa["z_full"])[1:-1], torch.from_numpy(pb["z_full"])[1:-1]
+    xa, xb = torch.from_numpy(pa["xyz_full"])[0, 1:-1], torch.from_numpy(pb["xyz_full"])[0, 1:-1]
+    st = den.prepare_structures([xa, xb], [za, zb])
+    job = den.make_job(st, [0, 1, 1])
+    x = synth.gaussian((46 + 87 + 87, 3), 99).to(DEV)
+    out = den.forward(job, x, 700)
+    sa = den.prepare_structures([xa], [za])
+    sb = den.prepare_structures([xb], [zb])
+    oa = den.forward(den.make_job(sa, [0]), x[:46], 700)
+    ob = den.forward(den.make_job(sb, [0, 0]), x[46:], 700)
+    assert torch.equal(out, torch.cat([oa, ob]))
+
+
+@pytest.mark.parametrize("name", list(cases.LOOP_CASES))
+def test_sample_loop(den, sd, name):
+    L, B, seed, T = cases.LOOP_CASES[name]
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    st = structures_of(den, prot)
+    job = den.make_job(st, list(range(B)))
+    x0 = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tables(T))
+    gold = np.load(cases.npz_path(f"g3_loop_{name}"))
+    assert rel_err(x0.cpu().view(B, L, 3), gold["sample"]) < (1e-4 if T > 10 else 2e-5)
+    if T <= 10:
+        cg_z, cg_xyz, _ = oden.batch_to_dense(batch)
+        ref = osam.p_sample_loop(sd, T, z, eps, cg_xyz, cg_z, mask, hoist_features=True)
+        assert rel_err(x0.cpu().view(B, L, 3), ref) < 2e-5
+
+
+def test_stepwise_equals_fused_loop(den, sd):
+    """codlad_denoiser_forward + codlad_ddpm_update per step == codlad_sample_loop."""
+    L, B, seed, T = cases.LOOP_CASES["L46_B2_T10"]
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    st = structures_of(den, prot)
+    job = den.make_job(st, list(range(B)))
+    tb = tables(T)
+    x = z.reshape(-1, 3).to(DEV)
+    for k, i in enumerate(range(T - 1, -1, -1)):
+        out = den.forward(job, x, tb.timestep_map[i])
+        x = den.ddpm_update(x, out, eps[k].reshape(-1, 3).to(DEV), tb, i)
+    fused = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tb)
+    assert torch.equal(x, fused)
+
+
+def test_deterministic_replay(den, sd):
+    L, B, seed, T = cases.LOOP_CASES["L87_B2_T10"]
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    st = structures_of(den, prot)
+    job = den.make_job(st, list(range(B)))
+    a = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tables(T))
+    b = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tables(T))
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+def _vae_sd(vae_type, dataname, real_c2=False):
+    vsd = synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED, c2_like_map_out=real_c2)
+    if real_c2:
+        w = np.load(cases.npz_path("c2_decoder_weights"))
+        for k in w.files:
+            vsd[k] = torch.from_numpy(w[k])
+    return vsd
+
+
+@pytest.mark.parametrize("vae_type,dataname", [("N6", "PED"), ("K3", "PDB"), ("K4", "Atlas")])
+def test_vq_lookup_bit_exact(vae_type, dataname):
+    gold = np.load(cases.npz_path(f"g4_vq_{vae_type}"))
+    mean, std = synth.norm_stats(dataname, vae_type)
+    dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED), DEV, mean, std)
+    x = synth.gaussian((4, 77, 3), 123 + len(dataname))
+    idx, zq, lat = dec.vq(x.to(DEV))
+    assert torch.equal(lat.cpu(), torch.from_numpy(gold["latent"]))
+    assert torch.equal(idx.cpu(), torch.from_numpy(gold["idx"]))
+    assert torch.equal(zq.cpu(), torch.from_numpy(gold["z_q"]))
+
+
+def test_vq_lookup_large_random_vs_oracle():
+    """200k latents incl. exact ties (duplicated codes): first index wins, indices bit-exact."""
+    vsd = synth.vqvae_state_dict("N6", "PED", cases.VAE_SEED)
+    cb = odec.codebook_of(vsd).clone()
+    cb[100] = cb[7]; cb[4095] = cb[7]
+    vsd["quantize._codebook.embed"] = cb[None]
+    dec = Decoder(vsd, DEV)
+    lat = synth.gaussian((200000, 3), 77) * 5.0
+    lat[:64] = cb[7]
+    idx, zq, _ = dec.vq(lat.to(DEV), normalised=False)
+    ridx = odec.vq_lookup(lat, cb)[1]
+    assert torch.equal(idx.cpu(), ridx)
+    assert int(idx[0]) == 7
+
+
+@pytest.mark.parametrize("name", list(cases.DECODER_CASES) + ["realC2_L87_B2"])
+def test_ic_decode_and_xyz(name):
+    real = name.startswith("realC2")
+    L, B, seed, vae_type = cases.DECODER_CASES["N6_L87_B2" if real else name]
+    prot, batch, latent, dataname = cases.decoder_inputs(L, B, seed, vae_type)
+    vsd = _vae_sd(vae_type, dataname, real)
+    dec = Decoder(vsd, DEV)
+    idx, zq, _ = dec.vq(latent.to(DEV), normalised=False)
+    gold = np.load(cases.npz_path(f"g5_decode_{name}"))
+    if "idx" in gold.files:
+        assert torch.equal(idx.cpu(), torch.from_numpy(gold["idx"]))
+    ic = dec.ic_decode(zq.reshape(-1, 3), batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:],
+                       batch["CG_nbr_list"])
+    assert rel_err(ic, gold["ic_recon"]) < 2e-5
+    if not real:
+        og = batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)[:, :, 1:]
+        gold_ic = torch.from_numpy(gold["ic_recon"]).reshape(B, L, 13, 3)
+        xyz = dec.ic_to_xyz(og.to(DEV), gold_ic.to(DEV), prot["info"])
+        gx = torch.from_numpy(np.load(cases.npz_path(f"g6_xyz_{name}"))["xyz"])
+        assert xyz.shape == gx.shape
+        assert float((xyz.cpu() - gx).abs().max()) < 2e-4   # Angstrom
+
+
+@pytest.mark.parametrize("name", list(cases.E2E_CASES))
+def test_end_to_end(den, sd, name):
+    """noise -> xyz on the GPU vs the reference CPU path: RMSD <= 1e-4 A wherever the VQ codes agree;
+    a code may legitimately differ only where the reference's own top-2 margin is a near-tie."""
+    L, B, seed, T, vae_type, dataname = cases.E2E_CASES[name]
+    gold = np.load(cases.npz_path(f"g7_e2e_{name}"))
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    st = structures_of(den, prot)
+    job = den.make_job(st, list(range(B)))
+    x0 = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tables(T))
+    assert rel_err(x0.cpu().view(B, L, 3), gold["samples"]) < 1e-4
+    mean, std = synth.norm_stats(dataname, vae_type)
+    dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED), DEV, mean, std)
+    idx, zq, lat = dec.vq(x0)
+    differ = idx.cpu() != torch.from_numpy(gold["idx"])
+    assert not bool((differ & (torch.from_numpy(gold["margin"]) > 1e-2)).any())
+    ic = dec.ic_decode(zq, batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:], batch["CG_nbr_list"])
+    xyz = dec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)[:, :, 1:].to(DEV),
+                        ic.view(B, L, 13, 3), prot["info"])
+    if not bool(differ.any()):
+        rmsd = float(((xyz.cpu() - torch.from_numpy(gold["xyz"])) ** 2).sum(-1).mean().sqrt())
+        assert rmsd < 1e-4

@@ -1,0 +1,133 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol,
+the weight packer matches the library's own packer, schedule tables match the reference goldens,
+and the table builders (CSR, info tables, job node tables) are right.  No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from codlad_amd import _lib, synth
+from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
+from codlad_amd.weights import denoiser_tensors, decoder_tensors, pack_block
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "codlad_hip.h")).read()
+    declared = set(re.findall(r"\b(codlad_[a-z0-9_]+)\s*\(", header))
+    declared -= {"codlad_pack_block_host"} - {"codlad_pack_block_host"}
+    assert declared == set(_lib.exported_symbols())
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.codlad_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # pointer counts of the ctypes mirrors = those of the C structs (all members are pointers)
+    assert C.sizeof(_lib.EncLayer) == 26 * 8
+    assert C.sizeof(_lib.DecLayer) == 19 * 8
+    assert C.sizeof(_lib.DenoiserWeights) == (6 + 14 + 11) * 8 + 3 * 26 * 8 + 3 * 19 * 8
+    assert C.sizeof(_lib.Workspace) == 5 * 8
+
+
+def test_argument_errors_are_reported_not_crashed():
+    lib = _lib.lib()
+    rc = lib.codlad_vq_lookup(None, 10, None, None, None, 4096, None, None, None, None)
+    assert rc < 0 and b"null pointer" in lib.codlad_last_error()
+    rc = lib.codlad_ic_to_xyz(None, None, None, None, 1, 1, 1, None, None)
+    assert rc < 0
+
+
+def test_pack_block_matches_library_packer():
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(128, 384, generator=g)
+    blk = W[:, 128:256]
+    mine = pack_block(blk, 2.0)
+    src = np.ascontiguousarray(W.numpy())
+    dst = np.empty(16384, dtype=np.float32)
+    _lib.lib().codlad_pack_block_host(src.ctypes.data_as(C.c_void_p).value + 128 * 4, 384, C.c_float(2.0),
+                                      dst.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(mine.numpy(), dst)
+    # every source element appears exactly once
+    assert np.array_equal(np.sort(dst), np.sort(2.0 * blk.numpy().reshape(-1)))
+
+
+@pytest.mark.parametrize("T", ["10", "100", "250"])
+def test_schedule_tables_match_reference(T):
+    gold = np.load(cases.npz_path(f"g1_schedule_{T}"))
+    tb = Tables(named_betas("linear", 1000), space_timesteps(1000, T))
+    assert tb.timestep_map == gold["timestep_map"].tolist()
+    for k in ("betas", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+              "posterior_mean_coef2", "posterior_log_variance_clipped"):
+        np.testing.assert_array_equal(getattr(tb, k), gold[k], err_msg=k)
+    c = tb.step_coefficients()
+    np.testing.assert_array_equal(c[:, 5], gold["log_betas"].astype(np.float32))
+    assert c[0, 6] == 0 and (c[1:, 6] == 1).all()
+
+
+def test_space_timesteps_variants():
+    assert space_timesteps(300, [10, 15, 20]) == space_timesteps(300, "10,15,20")
+    assert len(space_timesteps(1000, "ddim50")) == 50
+    with pytest.raises(ValueError):
+        space_timesteps(10, "20")
+
+
+def test_denoiser_blob_covers_every_checkpoint_tensor():
+    sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
+    t = denoiser_tensors(sd)
+    # 96 packed 128x128 blocks + TS tables + plain tensors; total parameter mass is preserved
+    n_blocks = sum(1 for v in t.values() if v.numel() == 16384 and v.dim() == 1)
+    assert n_blocks == 3 * 18 + 3 * 13
+    mod = {("module." + k): v for k, v in sd.items()}
+    t2 = denoiser_tensors(mod)
+    assert all(torch.equal(t[k], t2[k]) for k in t)
+
+
+def test_decoder_tensors_both_variants_and_codebook_layouts():
+    for vt, dn in (("N6", "PED"), ("K3", "PDB")):
+        for layout in ("lucidrains", "inrepo"):
+            vsd = synth.vqvae_state_dict(vt, dn, cases.VAE_SEED, quantizer_layout=layout)
+            t, angle = decoder_tensors(vsd)
+            assert angle == (vt != "N6")
+            assert t["codebook"].shape == (4096, 3)
+            assert t["tor1_w0"].shape == ((50, 50) if angle else (40, 40))
+
+
+def test_csr_from_pairs_keeps_reference_scatter_order():
+    from codlad_amd.engine import Decoder
+    pairs = torch.tensor([[0, 1], [0, 3], [1, 2], [2, 3]])
+    ptr, src = Decoder.csr_from_pairs(pairs, 5)
+    assert ptr.tolist() == [0, 2, 4, 6, 8, 8]
+    # receiver 1: first the forward pair (1<-2), then the flipped one (1<-0)
+    assert src.tolist() == [1, 3, 2, 0, 3, 1, 0, 2]
+
+
+def test_info_tables_invert_the_reference_gather():
+    from codlad_amd.engine import info_tables
+    prot = synth.make_protein(30, 5)
+    permute, atom_idx, orders = prot["info"]
+    o, s2o, n_atoms = info_tables(prot["info"], 30, "cpu")
+    slots = torch.arange(30 * 14)
+    ref = slots[atom_idx][permute]          # what utils_ic.py:267 selects
+    back = torch.full((n_atoms,), -1, dtype=torch.long)
+    valid = s2o >= 0
+    back[s2o[valid].long()] = slots[valid]
+    assert torch.equal(back, ref)
+    bad = (permute, atom_idx, orders.clone())
+    bad[2][0, 0, 0] = 9                      # CB built from an atom that does not exist yet
+    with pytest.raises(AssertionError):
+        info_tables(bad, 30, "cpu")
+
+
+def test_product_code_never_imports_the_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "codlad_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
