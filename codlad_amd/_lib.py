@@ -99,12 +99,20 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
 
 
+class _TensorPtr(C.c_void_p):
+    """c_void_p that keeps its tensor alive for as long as the argument object lives, i.e. until
+    the foreign call has been enqueued.  (A bare integer would let a temporary such as
+    `x.contiguous()` be freed - and its block reused by the next temporary - before the launch.)"""
+
+
 def ptr(t):
     """Device (or host) pointer of a contiguous tensor, None -> NULL."""
     if t is None:
         return None
     assert t.is_contiguous(), "non-contiguous tensor handed to the C ABI"
-    return C.c_void_p(t.data_ptr())
+    p = _TensorPtr(t.data_ptr())
+    p._keepalive = t
+    return p
 
 
 def stream_ptr(device=None):

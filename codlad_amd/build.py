@@ -10,6 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
 SOURCES = ["api.hip", "denoiser_kernels.hip", "features_kernels.hip", "decode_kernels.hip"]
+# Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
+# and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
+EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "codlad_hip.h")]
 
 
@@ -37,7 +40,8 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(d) for d in [src] + HEADERS):
-            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(s, []) + \
+                  ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -245,32 +245,23 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
         for (int k = 0; k < 6; ++k) a.logits[(size_t)n * 6 + k] = o[k];
         return;
     }
-    const float c_recip = a.coef[0], c_recipm1 = a.coef[1], pc1 = a.coef[2], pc2 = a.coef[3];
-    const float min_log = a.coef[4], max_log = a.coef[5], nonzero = a.coef[6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float xt = a.x[(size_t)n * 3 + k];
-        const float frac = (o[3 + k] + 1.0f) / 2.0f;
-        const float logvar = frac * max_log + (1.0f - frac) * min_log;
-        const float x0 = c_recip * xt - c_recipm1 * o[k];
-        const float mean_ = pc1 * x0 + pc2 * xt;
-        a.x[(size_t)n * 3 + k] = mean_ + nonzero * expf(0.5f * logvar) * a.noise[(size_t)n * 3 + k];
-    }
+    for (int k = 0; k < 3; ++k)
+        a.x[(size_t)n * 3 + k] = ddpm_step(a.x[(size_t)n * 3 + k], o[k], o[3 + k], a.coef,
+                                           a.noise[(size_t)n * 3 + k]);
 }
 
 // stand-alone DDPM update on a model output [n][6]
-__global__ void ddpm_kernel(const float *x, const float *out, const float *noise, float c_recip,
-                            float c_recipm1, float pc1, float pc2, float min_log, float max_log,
-                            float nonzero, int n_nodes, float *x_out) {
+struct DdpmCoef {
+    float c[8];
+};
+
+__global__ void ddpm_kernel(const float *x, const float *out, const float *noise, DdpmCoef cf,
+                            int n_nodes, float *x_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes * 3) return;
     const int n = i / 3, k = i - 3 * n;
-    const float xt = x[i];
-    const float frac = (out[n * 6 + 3 + k] + 1.0f) / 2.0f;
-    const float logvar = frac * max_log + (1.0f - frac) * min_log;
-    const float x0 = c_recip * xt - c_recipm1 * out[n * 6 + k];
-    const float mean_ = pc1 * x0 + pc2 * xt;
-    x_out[i] = mean_ + nonzero * expf(0.5f * logvar) * noise[i];
+    x_out[i] = ddpm_step(x[i], out[n * 6 + k], out[n * 6 + 3 + k], cf.c, noise[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,10 +438,10 @@ extern "C" int codlad_ddpm_update(const float *x, const float *model_out, const 
                                   const float *coef_host, int n_nodes, float *x_out, void *stream) {
     CODLAD_REQUIRE(x && model_out && noise && coef_host && x_out, "null pointer");
     CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
-    const float *c = coef_host;
+    DdpmCoef cf;
+    for (int k = 0; k < 8; ++k) cf.c[k] = coef_host[k];
     hipLaunchKernelGGL(ddpm_kernel, dim3((n_nodes * 3 + 255) / 256), dim3(256), 0,
-                       (hipStream_t)stream, x, model_out, noise, c[0], c[1], c[2], c[3], c[4], c[5],
-                       c[6], n_nodes, x_out);
+                       (hipStream_t)stream, x, model_out, noise, cf, n_nodes, x_out);
     return codlad_check_launch("codlad_ddpm_update");
 }
 

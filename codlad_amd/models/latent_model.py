@@ -1,0 +1,204 @@
+"""Drop-in for the reference's models/latent_model.py (`MPNN_models['mpnn_diffusion']`).
+
+The module keeps the reference's constructor arguments, parameter names and shapes (so
+`load_state_dict(strict=True)` of a `protein_weights_*.pt` checkpoint works unchanged, reference
+test.py:264-286) and its forward signature (models/latent_model.py:175), but holds no PyTorch
+math: forward hands the batch to the HIP kernels of libcodlad_hip.so.  Running it on the CPU, or
+without the built library, raises.
+"""
+import torch
+import torch.nn as nn
+
+from ..engine import Denoiser
+
+HIDDEN = 128
+
+
+class _FeedForwardParams(nn.Module):          # reference PositionWiseFeedForward (parameters only)
+    def __init__(self, num_hidden, num_ff):
+        super().__init__()
+        self.W_in = nn.Linear(num_hidden, num_ff, bias=True)
+        self.W_out = nn.Linear(num_ff, num_hidden, bias=True)
+
+
+def _adaln(hidden, n_chunks):
+    # nn.Sequential(SiLU, Linear): the Linear is entry "1", as in the reference checkpoints
+    return nn.Sequential(nn.SiLU(), nn.Linear(hidden, n_chunks * hidden, bias=True))
+
+
+class _EncLayerParams(nn.Module):             # reference EncLayer_diffusion
+    def __init__(self, num_hidden, num_in):
+        super().__init__()
+        self.W1 = nn.Linear(num_hidden + num_in, num_hidden, bias=True)
+        self.W2 = nn.Linear(num_hidden, num_hidden, bias=True)
+        self.W3 = nn.Linear(num_hidden, num_hidden, bias=True)
+        self.W11 = nn.Linear(num_hidden + num_in, num_hidden, bias=True)
+        self.W12 = nn.Linear(num_hidden, num_hidden, bias=True)
+        self.W13 = nn.Linear(num_hidden, num_hidden, bias=True)
+        self.dense = _FeedForwardParams(num_hidden, num_hidden * 4)
+        self.adaLN_modulation = _adaln(num_hidden, 9)
+
+
+class _DecLayerParams(nn.Module):             # reference DecLayer_diffusion
+    def __init__(self, num_hidden, num_in):
+        super().__init__()
+        self.W1 = nn.Linear(num_hidden + num_in, num_hidden, bias=True)
+        self.W2 = nn.Linear(num_hidden, num_hidden, bias=True)
+        self.W3 = nn.Linear(num_hidden, num_hidden, bias=True)
+        self.dense = _FeedForwardParams(num_hidden, num_hidden * 4)
+        self.adaLN_modulation = _adaln(num_hidden, 6)
+
+
+class _PositionalParams(nn.Module):
+    def __init__(self, num_embeddings, max_relative_feature=32):
+        super().__init__()
+        self.linear = nn.Linear(2 * max_relative_feature + 1 + 1, num_embeddings)
+
+
+class _FeatureParams(nn.Module):              # reference CA_ProteinFeatures
+    def __init__(self, edge_features, num_positional_embeddings=16, num_rbf=16):
+        super().__init__()
+        self.embeddings = _PositionalParams(num_positional_embeddings)
+        self.edge_embedding = nn.Linear(num_positional_embeddings + num_rbf * 9 + 7, edge_features, bias=False)
+        self.norm_edges = nn.LayerNorm(edge_features)
+
+
+class _TimestepParams(nn.Module):             # reference TimestepEmbedder
+    def __init__(self, hidden, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden, hidden, bias=True))
+
+
+class _FinalParams(nn.Module):                # reference FinalLayer
+    def __init__(self, hidden, out_size):
+        super().__init__()
+        self.linear = nn.Linear(hidden, out_size, bias=True)
+        self.adaLN_modulation = _adaln(hidden, 2)
+
+
+class ProteinMPNN_diffusion_new(nn.Module):
+    """Same constructor surface as the reference class (models/latent_model.py:78-99)."""
+
+    def __init__(self, node_features=128, edge_features=128, hidden_dim=128, num_encoder_layers=3,
+                 num_decoder_layers=3, vocab=30, k_neighbors=64, augment_eps=0.05, dropout=0.6,
+                 ca_only=True, input_size=36, class_dropout_prob=0.1, unconditional=False,
+                 diffusion=False, use_input_decoding_order=False, decoder_mask=True,
+                 use_seq_in_encoder=False, self_condition=False, final_adln=True):
+        super().__init__()
+        unsupported = []
+        if (node_features, edge_features, hidden_dim) != (128, 128, 128):
+            unsupported.append("hidden sizes other than 128")
+        if (num_encoder_layers, num_decoder_layers) != (3, 3):
+            unsupported.append("layer counts other than 3+3")
+        if k_neighbors != 64 or vocab != 30 or not ca_only:
+            unsupported.append("k_neighbors != 64 / vocab != 30 / full-backbone features")
+        if augment_eps != 0.0 or decoder_mask or not use_seq_in_encoder or use_input_decoding_order:
+            unsupported.append("anything but the `mpnn_diffusion` configuration")
+        if self_condition or not final_adln or diffusion != "diffusion" or input_size != 3:
+            unsupported.append("self-conditioning / plain output head / non-DDPM heads / latent_size != 3")
+        if unsupported:
+            raise NotImplementedError("the HIP path builds the reference's mpnn_diffusion model only; "
+                                      "not supported: " + "; ".join(unsupported))
+        self.self_condition = self_condition
+        self.decoder_mask, self.use_seq_in_encoder, self.final_adln = decoder_mask, use_seq_in_encoder, final_adln
+        self.hidden_dim = hidden_dim
+        self.t_embedder = _TimestepParams(hidden_dim)
+        self.x_in = nn.Linear(input_size, hidden_dim)
+        self.features = _FeatureParams(edge_features)
+        self.W_e = nn.Linear(edge_features, hidden_dim, bias=True)
+        self.W_s = nn.Embedding(vocab, hidden_dim)
+        self.encoder_layers = nn.ModuleList([_EncLayerParams(hidden_dim, hidden_dim * 2)
+                                             for _ in range(num_encoder_layers)])
+        self.decoder_layers = nn.ModuleList([_DecLayerParams(hidden_dim, hidden_dim * 3)
+                                             for _ in range(num_decoder_layers)])
+        self.W_out = _FinalParams(hidden_dim, input_size * 2)
+        # same initialisation policy as the reference (latent_model.py:151-165)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for layer in list(self.encoder_layers) + list(self.decoder_layers) + [self.W_out]:
+            nn.init.constant_(layer.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(layer.adaLN_modulation[-1].bias, 0)
+        self._engine = None
+        self._engine_key = None
+        self._job_cache = {}
+
+    # -- HIP engine plumbing ---------------------------------------------------------------------
+    def engine(self):
+        """Packed device weights; rebuilt whenever a parameter changed or moved."""
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        if self._engine is None or key != self._engine_key:
+            dev = next(self.parameters()).device
+            self._engine = Denoiser(self.state_dict(), dev)
+            self._engine_key = key
+            self._job_cache.clear()
+        return self._engine
+
+    def job_for(self, batch, n_rep):
+        """Ragged job for a batch dict (reference CG_collate schema), the batch repeated n_rep
+        times along the sample axis (the reference doubles it: test.py:505, latent_model.py:178-186).
+        The step-invariant features are cached per CG_nxyz tensor, so a sampling loop that calls
+        forward 100 times pays for them once."""
+        cg = batch["CG_nxyz"]
+        num = batch["num_CGs"]
+        key = (cg.data_ptr(), cg._version, tuple(cg.shape), num.data_ptr(), num._version, n_rep)
+        if key not in self._job_cache:
+            eng = self.engine()
+            lens = num.tolist()
+            xyz = torch.split(cg[:, 1:], lens)
+            z = torch.split(cg[:, 0].long(), lens)
+            st = eng.prepare_structures(list(xyz), list(z))
+            self._job_cache = {key: (eng.make_job(st, list(range(len(lens))) * n_rep), lens, cg, num)}
+        return self._job_cache[key][0], self._job_cache[key][1]
+
+    @staticmethod
+    def _check_mask(mask, lens, n_rep):
+        if mask is None:
+            return
+        L = max(lens)
+        want = torch.arange(L, device=mask.device)[None, :] < torch.tensor(lens * n_rep, device=mask.device)[:, None]
+        if mask.shape != want.shape or not torch.equal(mask.bool(), want):
+            raise ValueError("mask must be the length mask of batch['num_CGs'] (reshape_and_create_mask)")
+
+    def forward(self, x, t, y, mask=None, batch=None, x_self_cond=None):
+        """x [N,L,C], t [N] (all equal), y ignored (as in the reference), mask [N,L] -> [N,L,2C]."""
+        if not x.is_cuda:
+            raise RuntimeError("ProteinMPNN_diffusion_new (codlad_amd) runs on the MI355X only; "
+                               "move the model and inputs to cuda")
+        if x_self_cond is not None:
+            raise NotImplementedError("self-conditioning is not part of the mpnn_diffusion path")
+        B = int(batch["num_CGs"].shape[0])
+        N = int(x.shape[0])
+        if N % B:
+            raise ValueError("x batch size must be a multiple of the number of structures in batch")
+        n_rep = N // B
+        job, lens = self.job_for(batch, n_rep)
+        self._check_mask(mask, lens, n_rep)
+        tt = t.reshape(-1)
+        t0 = int(tt[0])
+        if tt.numel() > 1 and not bool((tt == t0).all()):
+            raise NotImplementedError("per-sample timesteps: the sampler uses one timestep per call")
+        L = x.shape[1]
+        if len(set(lens)) == 1:
+            flat = x.reshape(-1, x.shape[-1])
+        else:  # padded mixed-length batch -> ragged
+            flat = torch.cat([x[s, :n] for s, n in enumerate(lens * n_rep)], dim=0)
+        out = self.engine().forward(job, flat, t0)
+        if len(set(lens)) == 1:
+            return out.view(N, L, -1)
+        res = out.new_zeros(N, L, out.shape[-1])
+        o = 0
+        for s, n in enumerate(lens * n_rep):
+            res[s, :n] = out[o:o + n]
+            o += n
+        return res
+
+
+def mpnn_diffusion(**kwargs):
+    return ProteinMPNN_diffusion_new(augment_eps=0.0, decoder_mask=False, use_seq_in_encoder=True, **kwargs)
+
+
+MPNN_models = {
+    'mpnn_diffusion': mpnn_diffusion,
+}

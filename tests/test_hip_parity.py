@@ -76,9 +76,20 @@ def test_features_prepass(den, sd, name):
     hE0 = torch.nn.functional.linear(E, sd["W_e.weight"], sd["W_e.bias"])
     K = min(64, L)
     got_idx = st.E_idx.cpu().view(B, L, 64)[:, :, :K].long()
-    assert torch.equal(got_idx, E_idx)                      # neighbour lists: exact
-    gold = np.load(cases.npz_path(f"g2_forward_{name}"))
-    assert torch.equal(got_idx, torch.from_numpy(gold["E_idx"]))
+    gold_idx = torch.from_numpy(np.load(cases.npz_path(f"g2_forward_{name}"))["E_idx"])
+    # Neighbour lists must be identical up to the order of EXACTLY tied distances (the synthetic
+    # traces have a fixed 3.8 A step, so d(i,i-1) == d(i,i+1) bit for bit is common, and
+    # torch.topk leaves the order of equal keys unspecified): same neighbour set per residue and
+    # the same, bitwise equal, ascending distance sequence.
+    dX = cg_xyz[:, None, :, :] - cg_xyz[:, :, None, :]
+    D = torch.sqrt(torch.sum(dX ** 2, 3) + 1e-6)
+    for ref_idx in (E_idx, gold_idx):
+        assert torch.equal(torch.gather(D, 2, got_idx), torch.gather(D, 2, ref_idx))
+        assert torch.equal(got_idx.sort(-1).values, ref_idx.sort(-1).values)
+    assert bool((got_idx[:, :, 0] == torch.arange(L)[None]).all())         # self comes first
+    # compare edge features edge by edge: bring the oracle's rows into this kernel's neighbour order
+    perm = (got_idx[..., :, None] == E_idx[..., None, :]).float().argmax(-1)   # [B,L,K]
+    hE0 = torch.gather(hE0, 2, perm[..., None].expand(-1, -1, -1, 128))
     got = st.h_E0.cpu().view(B, L, 64, 128)[:, :, :K]
     assert rel_err(got, hE0) < 5e-6
 
