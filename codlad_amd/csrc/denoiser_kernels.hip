@@ -466,6 +466,31 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
     return codlad_check_launch("codlad_sample_loop");
 }
 
+// Single launch of one of the two edge kernels on encoder layer 0 (reads h_E0 and the P/Q left by
+// a previous forward; idempotent) - lets bench.py time the dominant kernel with HIP events.
+extern "C" int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *node_info,
+                                        int n_nodes, const int32_t *E_idx, const float *h_E0,
+                                        const float *mods_t, const codlad_workspace *ws, int which,
+                                        void *stream) {
+    CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && mods_t, "null pointer");
+    CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
+    CODLAD_REQUIRE(n_nodes > 0 && (which == 0 || which == 1), "bad arguments");
+    const size_t NS = (size_t)n_nodes * HD;
+    const codlad_enc_layer &L = w->enc[0];
+    EdgeArgs ea = {};
+    ea.node_info = reinterpret_cast<const int4 *>(node_info); ea.E_idx = E_idx; ea.n_nodes = n_nodes;
+    ea.hE_in = h_E0; ea.in_by_src = 1;
+    if (which == 0) {
+        ea.P = ws->PQ; ea.Q = ws->PQ + NS; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
+    } else {
+        ea.hE_out = ws->hE; ea.P = ws->PQ + 2 * NS; ea.Q = ws->PQ + 3 * NS;
+        ea.W1 = L.W11e; ea.W2 = L.W12; ea.W3 = L.W13; ea.b2 = L.b12; ea.b3 = L.b13;
+        ea.mods3 = mods_t + 6 * HD;
+    }
+    launch_edge(which == 1, ea, (hipStream_t)stream);
+    return codlad_check_launch("codlad_bench_edge_launch");
+}
+
 // ---------------------------------------------------------------------------------------------
 // self-test of the chain primitive
 // ---------------------------------------------------------------------------------------------

@@ -216,11 +216,13 @@ class Decoder:
         ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         return ptr, src
 
-    def ic_decode(self, z_q, cg_z, cg_xyz, pairs):
-        """z_q [M,3], cg_z [M], cg_xyz [M,3], pairs [E,2] (flat node indices) -> ic [M,13,3]."""
+    def ic_decode(self, z_q, cg_z, cg_xyz, pairs=None, csr=None):
+        """z_q [M,3], cg_z [M], cg_xyz [M,3] and either the undirected CG pairs [E,2] (flat node
+        indices, as in batch['CG_nbr_list']) or a prebuilt csr = (ptr, src) -> ic [M,13,3]."""
         _require_cuda(z_q, "z_q")
         M = z_q.shape[0]
-        ptr, src = self.csr_from_pairs(pairs.to(self.device), M)
+        ptr, src = csr if csr is not None else self.csr_from_pairs(pairs.to(self.device), M)
+        assert ptr.numel() == M + 1 and ptr.dtype == torch.int32 and src.dtype == torch.int32
         scratch = torch.empty(M, 200, dtype=torch.float32, device=self.device)
         ic = torch.empty(M, 13, 3, dtype=torch.float32, device=self.device)
         rc = self.lib.codlad_ic_decode(C.byref(self.weights.struct), _lib.ptr(z_q.contiguous().float()),

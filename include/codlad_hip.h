@@ -169,6 +169,14 @@ int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *order
                      const int32_t *slot_to_out, int B, int L, int n_atoms, float *xyz_out,
                      void *stream);
 
+/* Measurement hook: ONE launch of the message kernel (which = 0) or the edge-update kernel
+ * (which = 1) of encoder layer 0 on a job whose workspace holds the state of a previous forward.
+ * Idempotent (reads h_E0, P, Q; writes S or hE).  Used by bench.py to time the dominant kernel. */
+int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *node_info,
+                             int n_nodes, const int32_t *E_idx, const float *h_E0,
+                             const float *mods_t, const codlad_workspace *ws, int which,
+                             void *stream);
+
 /* Self-test of the MFMA chain primitive: Y[n][:] = act(W @ X[n][:] + bias), n < 32*tiles.
  * act: 0 = none, 1 = exact-erf GELU. */
 int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X, int n_rows,
