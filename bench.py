@@ -149,6 +149,7 @@ def cpu_baseline():
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    cores = min(cores, 16)   # a one-GPU box owns 16 host cores; more threads only oversubscribe
     torch.set_num_threads(cores)
     sd = synth.denoiser_state_dict(WEIGHT_SEED)
     vsd = synth.vqvae_state_dict("N6", "PED", VAE_SEED)
