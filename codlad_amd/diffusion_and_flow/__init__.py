@@ -1,0 +1,148 @@
+"""Drop-in for the reference's `diffusion_and_flow.create_diffusion` (sampling half).
+
+Same call surface as the reference (`diffusion_and_flow/__init__.py:10-60`): the returned object has
+`.p_sample_loop(model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+progress)`, `.p_sample_loop_progressive`, `.p_sample`, the schedule tables and `timestep_map`.
+The arithmetic is on the GPU: when `model` is the forward of a codlad_amd `ProteinMPNN_diffusion_new`
+the whole loop is one `codlad_sample_loop` call; any other CUDA callable is stepped with
+`codlad_ddpm_update`.  Training losses are out of scope.
+"""
+import enum
+
+import torch
+
+from .schedule import Tables, named_betas, space_timesteps
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class SpacedDiffusion(Tables):
+    """Respaced ancestral sampler (reference respace.py:65-114 + gaussian_diffusion.py:404-547),
+    epsilon-prediction mean with learned-range variance, which is what `create_diffusion`'s
+    defaults and test.py select."""
+
+    def __init__(self, use_timesteps, betas, model_mean_type=ModelMeanType.EPSILON,
+                 model_var_type=ModelVarType.LEARNED_RANGE, loss_type=None, self_condition=False):
+        if model_mean_type is not ModelMeanType.EPSILON or model_var_type is not ModelVarType.LEARNED_RANGE:
+            raise NotImplementedError("only epsilon prediction with LEARNED_RANGE variance is built "
+                                      "(the configuration test.py samples with)")
+        if self_condition:
+            raise NotImplementedError("self-conditioning is not on the mpnn_diffusion sampling path")
+        super().__init__(betas, set(use_timesteps))
+        self.use_timesteps = set(use_timesteps)
+        self.original_num_steps = len(betas)
+        self.model_mean_type, self.model_var_type = model_mean_type, model_var_type
+        self.loss_type, self.self_condition = loss_type, False
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _hip_module(model):
+        from ..models.latent_model import ProteinMPNN_diffusion_new
+        owner = getattr(model, "__self__", model)
+        return owner if isinstance(owner, ProteinMPNN_diffusion_new) else None
+
+    @staticmethod
+    def _check_args(clip_denoised, denoised_fn, cond_fn):
+        if clip_denoised or denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("clip_denoised / denoised_fn / cond_fn are not used by the "
+                                      "reference's sampling call (test.py:533) and are not built")
+
+    def _draw_noise(self, x, generator=None):
+        """T draws of randn_like(x), in loop order, consuming the device RNG stream exactly as the
+        reference's per-step `th.randn_like(x)` does (gaussian_diffusion.py:440)."""
+        return torch.stack([torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=generator)
+                            for _ in range(self.num_timesteps)])
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, step_noise=None):
+        """Returns x_0 with `shape`.  `step_noise` [T, *shape] optionally supplies the per-step noise
+        explicitly (loop order) instead of drawing it from the device RNG."""
+        self._check_args(clip_denoised, denoised_fn, cond_fn)
+        model_kwargs = model_kwargs or {}
+        mod = self._hip_module(model)
+        if mod is None:
+            final = None
+            for final in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                        model_kwargs=model_kwargs, device=device,
+                                                        step_noise=step_noise):
+                pass
+            return final["sample"]
+        if device is None:
+            device = next(mod.parameters()).device
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        if not img.is_cuda:
+            raise RuntimeError("p_sample_loop (codlad_amd) runs on the MI355X only")
+        eps = step_noise if step_noise is not None else self._draw_noise(img)
+        batch = model_kwargs["batch"]
+        n_rep = img.shape[0] // int(batch["num_CGs"].shape[0])
+        job, lens = mod.job_for(batch, n_rep)
+        mod._check_mask(model_kwargs.get("mask"), lens, n_rep)
+        if len(set(lens)) != 1:
+            raise NotImplementedError("fused loop on a padded mixed-length batch; pass equal-length "
+                                      "structures per call (what the reference's loaders produce)")
+        T = self.num_timesteps
+        x0 = mod.engine().sample(job, img.reshape(-1, img.shape[-1]), eps.reshape(T, -1, img.shape[-1]), self)
+        return x0.view(img.shape)
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                  cond_fn=None, model_kwargs=None, device=None, progress=False,
+                                  step_noise=None):
+        """Generic stepping for any CUDA model callable: model(x, t, **kwargs) -> [N,L,2C]."""
+        self._check_args(clip_denoised, denoised_fn, cond_fn)
+        model_kwargs = model_kwargs or {}
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        for k, i in enumerate(range(self.num_timesteps - 1, -1, -1)):
+            t = torch.tensor([i] * shape[0], device=img.device)
+            eps = step_noise[k] if step_noise is not None else torch.randn_like(img)
+            out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, noise=eps)
+            yield out
+            img = out["sample"]
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                 x_self_cond=None, noise=None):
+        self._check_args(clip_denoised, denoised_fn, cond_fn)
+        if not x.is_cuda:
+            raise RuntimeError("p_sample (codlad_amd) runs on the MI355X only")
+        from .. import _lib
+        i = int(t.reshape(-1)[0])
+        map_t = torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)[t]   # respace.py:124-129
+        model_out = model(x, map_t, **(model_kwargs or {}))
+        if noise is None:
+            noise = torch.randn_like(x)
+        C = x.shape[-1]
+        assert model_out.shape[-1] == 2 * C == 6, "latent_size 3 only"
+        import ctypes
+        import numpy as np
+        coef = np.ascontiguousarray(self.step_coefficients()[i])
+        xs = x.contiguous().float()
+        out = torch.empty_like(xs)
+        rc = _lib.lib().codlad_ddpm_update(_lib.ptr(xs), _lib.ptr(model_out.contiguous().float()),
+                                           _lib.ptr(noise.contiguous().float()),
+                                           coef.ctypes.data_as(ctypes.c_void_p), xs.numel() // 3,
+                                           _lib.ptr(out), _lib.stream_ptr(x.device))
+        _lib.check(rc, "codlad_ddpm_update")
+        return {"sample": out, "pred_xstart": None}
+
+
+def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, rescale_learned_sigmas=False,
+                     sigma_small=False, predict_xstart=False, learn_sigma=True, diffusion_steps=1000,
+                     self_condition=False):
+    if timestep_respacing is None or timestep_respacing == "":
+        timestep_respacing = [diffusion_steps]
+    if predict_xstart or not learn_sigma:
+        raise NotImplementedError("x0-prediction / fixed-sigma samplers are not on the built path")
+    return SpacedDiffusion(use_timesteps=space_timesteps(diffusion_steps, timestep_respacing),
+                           betas=named_betas(noise_schedule, diffusion_steps),
+                           model_mean_type=ModelMeanType.EPSILON, model_var_type=ModelVarType.LEARNED_RANGE,
+                           loss_type=None, self_condition=self_condition)

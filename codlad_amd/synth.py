@@ -113,15 +113,7 @@ def denoiser_state_dict(seed=1234, input_size=3):
     return sd
 
 
-NORM_STATS = {
-    # reference datasets/miu_and_sigma/{PED_N6,PDB_K3,Atlas_K4}_x_{mean,std}.pt (3 floats each)
-    ("PED", "N6"): ([1.068959355354309, -0.8994553089141846, 0.5618639588356018],
-                    [5.1957831382751465, 4.400951385498047, 5.270322799682617]),
-    ("PDB", "K3"): ([-1.5160585641860962, 0.6747006773948669, -0.5968422293663025],
-                    [8.262883186340332, 5.664480686187744, 6.969945907592773]),
-    ("Atlas", "K4"): ([-0.29618993401527405, 1.7351123094558716, -0.05292452499270439],
-                      [5.226162910461426, 7.113760948181152, 6.114980697631836]),
-}
+from .utils.dataset_module import _BUILTIN_STATS as NORM_STATS  # noqa: E402  (reference datasets/miu_and_sigma)
 
 
 def norm_stats(dataname="PED", vae_type="N6"):

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Inference entry point, drop-in for the sampling part of the reference's test.py
+(`--experiment latent` and `--experiment recon`), running on the HIP path.
+
+Kept from the reference (test.py:894-961): flag names and defaults, checkpoint locations
+(`./results/<exp>/protein_weights_{best,last,step_N}.pt` with `net_model` / `ema_model`, VQ-VAE
+directories of utils/model_module.py), the call sequence build_model -> create_diffusion ->
+p_sample_loop -> get_norm_feature -> latent_decode -> ic_to_xyz, and the output directory.
+Different by design: all ensemble members of a batch of frames are sampled in ONE launch set (the
+reference loops over them); the C2 prior call that only supplies `mask` (test.py:495) is replaced by
+the length mask; metrics and mdtraj I/O (out of scope) are replaced by saving coordinates as .npy.
+Data: `--data_process --data_files f.pkl ...` (pickled per-frame dicts, as the reference's
+--data_process branch reads them) or `--synthetic`
+(no PED/PDB/Atlas files ship with the reference).
+"""
+import argparse
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from codlad_amd import synth
+from codlad_amd.diffusion_and_flow import create_diffusion
+from codlad_amd.models.latent_model import MPNN_models
+from codlad_amd.utils.dataset_module import CG_collate, get_norm_feature
+from codlad_amd.utils.model_module import build_vae, get_vae_model, load_decoder_state
+from codlad_amd.utils.utils_ic import ic_to_xyz
+
+
+def build_model(args):
+    if "mpnn" not in args.backbone:
+        raise NotImplementedError(f"backbone {args.backbone!r}: only mpnn_diffusion is built")
+    return MPNN_models[args.backbone](input_size=args.latent_size, unconditional=not args.cond,
+                                      diffusion=args.model, self_condition=args.self_condition)
+
+
+def load_denoiser(args, device):
+    model = build_model(args)
+    if args.synthetic_weights:
+        model.load_state_dict(synth.denoiser_state_dict(1234), strict=True)
+    else:
+        tag = {"best": "best", "last": "last"}.get(args.model_step, f"step_{args.model_step}")
+        ckpt = torch.load(f"./results/{args.exp}/protein_weights_{tag}.pt", map_location="cpu")
+        sd = ckpt["net_model" if args.ckpt_type == "net" else "ema_model"]
+        try:
+            model.load_state_dict(sd, strict=True)
+        except RuntimeError:
+            model.load_state_dict({k[7:]: v for k, v in sd.items()}, strict=True)
+    return model.to(device).eval()
+
+
+def load_vae(args, device):
+    if args.synthetic_weights:
+        vae = build_vae(args.vae_type)
+        load_decoder_state(vae, synth.vqvae_state_dict(args.vae_type, args.data_type, 4321))
+        return vae.to(device).eval()
+    vae, _params = get_vae_model(args.vae_type, device=device, modelnum=args.modelnum)
+    return vae.to(device).eval()
+
+
+def iter_batches(args):
+    """Yields (name, batch dict, info)."""
+    if args.synthetic:
+        lengths = {"PED": (46, 87, 92, 129), "PDB": (60, 120, 200), "Atlas": (39, 155, 505)}[args.data_type]
+        for i, L in enumerate(lengths):
+            prot = synth.make_protein(L, 1000 + i, n_frames=args.synthetic_frames,
+                                      phospho=args.vae_type != "N6")
+            yield f"synthetic_L{L}", synth.make_batch(prot), prot["info"]
+        return
+    if not args.data_process:
+        raise SystemExit("pdb/xtc loading needs mdtraj (out of scope): use --data_process --data_files ... or --synthetic")
+    for path in args.data_files:
+        with open(path, "rb") as f:
+            testset, info = pickle.load(f)
+        bs = min(len(testset), 96)
+        for b in range(0, len(testset), bs):
+            yield os.path.basename(path), CG_collate([testset[i] for i in range(b, min(b + bs, len(testset)))]), info
+
+
+def main(args):
+    if not torch.cuda.is_available():
+        raise SystemExit("test.py (codlad_amd) needs an MI355X: there is no CPU path")
+    device = "cuda"
+    torch.set_grad_enabled(False)
+    torch.manual_seed(args.seed + args.sample_index)
+    np.random.seed(args.seed + args.sample_index)
+    if args.cfg_scale > 1.0:
+        raise NotImplementedError("cfg_scale > 1 calls model.forward_with_cfg, which the reference model "
+                                  "does not define (dead path)")
+    vae = load_vae(args, device)
+    if args.experiment == "latent":
+        model = load_denoiser(args, device)
+        diffusion = create_diffusion(str(args.num_sampling_steps), noise_schedule=args.noise_schedule,
+                                     predict_xstart=args.predict_xstart,
+                                     rescale_learned_sigmas=args.rescale_learned_sigmas, self_condition=False)
+    elif args.experiment != "recon":
+        raise NotImplementedError(f"experiment {args.experiment!r}: latent and recon are built")
+    save_dir = f"./logs/generated_samples_{args.sample_index}_{args.model_step}/{args.exp}_{args.data_type}"
+    os.makedirs(save_dir, exist_ok=True)
+    total, t_all = 0, time.time()
+    for name, batch, info in iter_batches(args):
+        batch = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in batch.items()}
+        B = int(batch["num_CGs"].shape[0])
+        L = int(batch["num_CGs"][0])
+        E = args.num_ensemble
+        st = time.time()
+        mask = torch.ones(B * E, L, dtype=torch.bool, device=device)
+        # E ensemble members of every frame = the batch repeated E times along the sample axis
+        rep = {k: v for k, v in batch.items()}
+        if args.experiment == "latent":
+            z = torch.randn(B * E, L, args.latent_size, device=device)
+            samples = diffusion.p_sample_loop(model.forward, z.shape, z, clip_denoised=False,
+                                              model_kwargs=dict(y=None, mask=mask, batch=rep), device=device)
+            samples = get_norm_feature(samples, args.vae_type, norm_channel=args.norm, norm_single=args.norm_single,
+                                       norm_in=False, dataname=args.data_type)
+        else:
+            mean = torch.tensor(synth.NORM_STATS[(args.data_type, args.vae_type)][0], device=device)
+            std = torch.tensor(synth.NORM_STATS[(args.data_type, args.vae_type)][1], device=device)
+            samples = torch.randn(B * E, L, args.latent_size, device=device) * std + mean   # stands in for the encoder
+        nres = L + 2
+        og = batch["OG_CG_nxyz"].reshape(-1, nres, 4)
+        xyz_all = []
+        for e in range(E):
+            _, ic_recon = vae.latent_decode(samples[e * B:(e + 1) * B], mask[:B], batch)
+            xyz_all.append(ic_to_xyz(og, ic_recon.reshape(-1, nres - 2, 13, 3), info))
+        xyz = torch.stack(xyz_all)                                   # [E, B, n_atoms, 3]
+        torch.cuda.synchronize()
+        dt = time.time() - st
+        total += B * E
+        np.save(os.path.join(save_dir, f"{name}_xyz_recon.npy"), xyz.cpu().numpy())
+        print(f"{name}: {B} frames x {E} members, L={L}, {xyz.shape[2]} atoms: {dt:.2f}s "
+              f"({B * E / dt:.1f} structures/s)", flush=True)
+    print(f"done: {total} structures in {time.time() - t_all:.1f}s -> {save_dir}")
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser("parameters")
+    # names and defaults as in the reference (test.py:894-961); flags of the ODE / flow samplers
+    # (--method, --atol, --rtol, --steps, --compute_nfe ...) are accepted and ignored
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--exp", default="experiment_cifar_default")
+    p.add_argument("--cond", action="store_true", default=False)
+    p.add_argument("--backbone", type=str, default="mpnn_diffusion")
+    p.add_argument("--latent_size", type=int, default=3)
+    p.add_argument("--cfg_scale", type=float, default=1.0)
+    p.add_argument("--model_step", type=str, default="best")
+    p.add_argument("--vae_type", type=str, default="N6")
+    p.add_argument("--cvae_type", type=str, default="C2")
+    p.add_argument("--model", type=str, default="diffusion")
+    p.add_argument("--num_sampling_steps", type=int, default=250)
+    p.add_argument("--norm", action="store_true", default=True)
+    p.add_argument("--norm_single", action="store_true", default=False)
+    p.add_argument("--data_type", type=str, default="PED")
+    p.add_argument("--data_process", action="store_true", default=False)
+    p.add_argument("--num_ensemble", type=int, default=1)
+    p.add_argument("--modelnum", type=int, default=-1)
+    p.add_argument("--self_condition", action="store_true", default=False)
+    p.add_argument("--predict_xstart", action="store_true", default=False)
+    p.add_argument("--rescale_learned_sigmas", action="store_true", default=False)
+    p.add_argument("--noise_schedule", type=str, default="linear", choices=["linear", "squaredcos_cap_v2"])
+    p.add_argument("--experiment", type=str, default="latent", choices=["genzprot", "recon", "latent"])
+    p.add_argument("--ckpt_type", type=str, default="net")
+    p.add_argument("--sample_index", type=int, default=0)
+    for ignored, kw in (("--compute_nfe", dict(action="store_true")), ("--iteration", dict(type=int, default=1000)),
+                        ("--n_sample", dict(type=int, default=50000)), ("--dataset", dict(default="cifar10")),
+                        ("--num_steps", dict(type=int, default=40)), ("--batch_size", dict(type=int, default=200)),
+                        ("--atol", dict(type=float, default=1e-5)), ("--rtol", dict(type=float, default=1e-5)),
+                        ("--method", dict(type=str, default="dopri5")), ("--steps", dict(type=int, default=2)),
+                        ("--feature_path", dict(type=str, default="./datasets/features_N6")),
+                        ("--gcn_layernorm", dict(action="store_true", default=True)),
+                        ("--forward_inf", dict(action="store_true", default=False))):
+        p.add_argument(ignored, **kw)
+    # additions
+    p.add_argument("--data_files", nargs="*", default=[], help="with --data_process: pickles of (list of frame dicts, info)")
+    p.add_argument("--synthetic", action="store_true", help="synthetic PED/PDB/Atlas-shaped proteins")
+    p.add_argument("--synthetic_frames", type=int, default=10)
+    p.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (no checkpoints ship)")
+    main(p.parse_args())

@@ -1,0 +1,245 @@
+"""The Python surface the reference's test.py uses, kept verbatim over the HIP
+kernels: MPNN_models, create_diffusion().p_sample_loop, get_vae_model/VAE.latent_decode,
+get_norm_feature, ic_to_xyz.  The CPU part checks names, checkpoint layouts and loud failure without
+a GPU; the GPU part replays the reference call sequence of test.py:504-582 against the goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from codlad_amd import synth
+from codlad_amd.diffusion_and_flow import create_diffusion
+from codlad_amd.models.latent_model import MPNN_models
+from codlad_amd.utils.dataset_module import CG_collate, get_norm_feature
+from codlad_amd.utils.model_module import build_vae, get_vae_model, load_decoder_state
+from codlad_amd.utils.utils_ic import ic_to_xyz
+from tests import cases
+
+
+def build_model():
+    # exactly reference test.py:190-198 (build_model) with the CLI defaults
+    return MPNN_models["mpnn_diffusion"](input_size=3, unconditional=True, diffusion="diffusion",
+                                         self_condition=False)
+
+
+# ---------------------------------------------------------------------------------------- CPU --
+def test_denoiser_checkpoint_layout_is_the_references():
+    model = build_model()
+    ref = synth.denoiser_state_dict(cases.WEIGHT_SEED)   # loaded strict=True into the reference in gen_golden
+    own = model.state_dict()
+    assert list(own.keys()) == list(ref.keys()) or set(own.keys()) == set(ref.keys())
+    assert len(own) == 108 and sum(v.numel() for v in own.values()) == 2449974
+    for k in ref:
+        assert own[k].shape == ref[k].shape, k
+    model.load_state_dict(ref, strict=True)
+    # DDP-style 'module.' prefix is handled the way test.py:279-286 does
+    wrapped = {"module." + k: v for k, v in ref.items()}
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(wrapped, strict=True)
+    model.load_state_dict({k[7:]: v for k, v in wrapped.items()}, strict=True)
+    # reference initialisation policy: adaLN heads start at zero
+    fresh = build_model()
+    assert float(fresh.W_out.adaLN_modulation[-1].weight.abs().sum()) == 0.0
+
+
+def test_unsupported_configurations_fail_loudly():
+    from codlad_amd.models.latent_model import ProteinMPNN_diffusion_new
+    with pytest.raises(NotImplementedError):
+        ProteinMPNN_diffusion_new(input_size=36, diffusion="diffusion")       # default ctor = not mpnn_diffusion
+    with pytest.raises(NotImplementedError):
+        MPNN_models["mpnn_diffusion"](input_size=3, diffusion="diffusion", self_condition=True)
+    with pytest.raises(NotImplementedError):
+        create_diffusion("100", predict_xstart=True)
+    with pytest.raises(NotImplementedError):
+        build_vae("C2")
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    model = build_model()
+    prot, batch, x, t, mask = cases.denoiser_inputs(20, 2, 11)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model.forward(x, t, None, mask=mask, batch=batch)
+    d = create_diffusion("10")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        d.p_sample_loop(model.forward, x.shape, x, clip_denoised=False, model_kwargs=dict(y=None, mask=mask, batch=batch))
+    vae = build_vae("N6")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        vae.latent_decode(x, mask, batch)
+    with pytest.raises(NotImplementedError):
+        vae.get_latent_cg(batch)
+
+
+def test_create_diffusion_surface():
+    d = create_diffusion("100", noise_schedule="linear", predict_xstart=False, rescale_learned_sigmas=False,
+                         self_condition=False)
+    assert d.num_timesteps == 100 and len(d.timestep_map) == 100 and d.original_num_steps == 1000
+    gold = np.load(cases.npz_path("g1_schedule_100"))
+    np.testing.assert_array_equal(d.betas, gold["betas"])
+    assert create_diffusion("").num_timesteps == 1000
+
+
+def test_vae_checkpoint_layouts(tmp_path):
+    for vt, dn in (("N6", "PED"), ("K3", "PDB"), ("K4", "Atlas")):
+        sd = synth.vqvae_state_dict(vt, dn, cases.VAE_SEED)
+        vae = build_vae(vt)
+        assert set(vae.state_dict().keys()) == set(sd.keys())
+        # encoder tensors and legacy dist_filter keys in a real checkpoint are skipped
+        extra = dict(sd)
+        extra["encoder.layers.0.weight"] = torch.zeros(3)
+        extra["equivaraintconv.message_blocks.0.dist_filter.weight"] = torch.zeros(40, 40)
+        load_decoder_state(vae, extra)
+        broken = dict(sd); broken.pop("map_out.bias")
+        with pytest.raises(RuntimeError, match="missing"):
+            load_decoder_state(build_vae(vt), broken)
+    # get_vae_model reads the reference's directory layout
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    torch.save(dict(synth.vqvae_state_dict("N6", "PED", 1)), d / "best_model.pt")
+    (d / "modelparams.json").write_text(json.dumps({"cg_cutoff": 21.0, "atom_cutoff": 9.0, "edgeorder": 2}))
+    model, params = get_vae_model("N6", modelpath=str(d), device="cpu", modelnum=999)
+    assert params["cg_cutoff"] == 21.0
+    assert torch.equal(model.map_out.weight, synth.vqvae_state_dict("N6", "PED", 1)["map_out.weight"])
+    # the shipped C2 decoder weights load into IC_Decoder (same module layout)
+    w = np.load(cases.npz_path("c2_decoder_weights"))
+    vae = build_vae("N6")
+    sd = synth.vqvae_state_dict("N6", "PED", 1)
+    sd.update({k: torch.from_numpy(w[k]) for k in w.files})
+    load_decoder_state(vae, sd)
+
+
+def test_get_norm_feature_roundtrip_and_values():
+    x = synth.gaussian((4, 9, 3), 3)
+    for vt, dn in (("N6", "PED"), ("K3", "PDB"), ("K4", "Atlas")):
+        y = get_norm_feature(x, vt, norm_in=False, dataname=dn)
+        mean, std = synth.norm_stats(dn, vt)
+        assert torch.equal(y, x * std + mean)
+        assert torch.allclose(get_norm_feature(y, vt, norm_in=True, dataname=dn), x, atol=1e-6)
+    assert torch.equal(get_norm_feature(x, "N6", norm_in=False, dataname="IDRome_test_7"),
+                       get_norm_feature(x, "N6", norm_in=False, dataname="PED"))
+
+
+def test_cg_collate_offsets():
+    prot = synth.make_protein(12, 3, n_frames=3)
+    single = [synth.make_batch(prot, [f]) for f in range(3)]
+    dicts = [{"CG_nxyz": b["CG_nxyz"], "OG_CG_nxyz": b["OG_CG_nxyz"], "CG_nbr_list": b["CG_nbr_list"],
+              "num_CGs": b["num_CGs"][0], "prot_idx": b["prot_idx"][0]} for b in single]
+    got = CG_collate(dicts)
+    want = synth.make_batch(prot)
+    for k in ("CG_nxyz", "OG_CG_nxyz", "CG_nbr_list", "num_CGs"):
+        assert torch.equal(got[k], want[k]), k
+
+
+# ---------------------------------------------------------------------------------------- GPU --
+gpu = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def to_dev(batch):
+    return {k: (v.to(DEV) if hasattr(v, "to") else v) for k, v in batch.items()}   # train_module.batch_to
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@gpu
+def test_model_forward_like_test_py():
+    model = build_model()
+    model.load_state_dict(synth.denoiser_state_dict(cases.WEIGHT_SEED), strict=True)
+    model = model.to(DEV).eval()
+    for name in ("L46_B2", "L87_B2"):
+        L, B, seed = cases.DENOISER_CASES[name]
+        prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+        batch = to_dev(batch)
+        gold = np.load(cases.npz_path(f"g2_forward_{name}"))
+        out = model(x.to(DEV), t.to(DEV), None, mask=mask.to(DEV), batch=batch)
+        assert out.shape == (B, L, 6) and rel_err(out, gold["out"]) < 1e-5
+        # the reference's doubled batch (test.py:505-512): [z;z], [mask;mask], same batch dict
+        x2, t2, m2 = torch.cat([x, x]).to(DEV), torch.cat([t, t]).to(DEV), torch.cat([mask, mask]).to(DEV)
+        out2 = model.forward(x2, t2, None, mask=m2, batch=batch)
+        assert out2.shape == (2 * B, L, 6)
+        assert torch.equal(out2[:B], out) and torch.equal(out2[B:], out)
+
+
+@gpu
+def test_padded_mixed_length_batch_is_treated_ragged():
+    model = build_model()
+    sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    name, lengths, seed = cases.PADDED_CASE
+    batch, x, t, mask = cases.padded_inputs(lengths, seed)
+    out = model(x.to(DEV), t.to(DEV), None, mask=mask.to(DEV), batch=to_dev(batch)).cpu()
+    # each sample equals the same structure run alone (no padding semantics), padded rows are zero
+    from oracle import denoiser as oden
+    off = 0
+    for s, L in enumerate(lengths):
+        cg = batch["CG_nxyz"][off:off + L]
+        ref = oden.forward(sd, x[s:s + 1, :L], t[:1], cg[None, :, 1:], cg[None, :, 0].long(),
+                           torch.ones(1, L, dtype=torch.bool))
+        assert rel_err(out[s, :L], ref[0]) < 1e-5
+        assert float(out[s, L:].abs().sum()) == 0.0
+        off += L
+
+
+@gpu
+def test_p_sample_loop_like_test_py():
+    model = build_model()
+    model.load_state_dict(synth.denoiser_state_dict(cases.WEIGHT_SEED), strict=True)
+    model = model.to(DEV).eval()
+    L, B, seed, T = cases.LOOP_CASES["L87_B2_T10"]
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    batch = to_dev(batch)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    gold = np.load(cases.npz_path("g3_loop_L87_B2_T10"))
+    diffusion = create_diffusion(str(T), noise_schedule="linear", predict_xstart=False,
+                                 rescale_learned_sigmas=False, self_condition=False)
+    # test.py:504-535: doubled batch, model_kwargs with y / mask / batch, chunk(2)[0]
+    cat_z = torch.cat([z, z], 0).to(DEV)
+    cat_mask = torch.cat([mask, mask], 0).to(DEV)
+    batch["randn"] = torch.randn(cat_z.shape[0], cat_z.shape[1], device=DEV)
+    kwargs = dict(y=torch.zeros(2 * B, L, 36, device=DEV), mask=cat_mask, batch=batch)
+    eps2 = torch.cat([eps, synth.gaussian(eps.shape, 5)], dim=1).to(DEV)     # second half: other noise
+    samples = diffusion.p_sample_loop(model.forward, cat_z.shape, cat_z, clip_denoised=False,
+                                      model_kwargs=kwargs, progress=True, device=DEV, step_noise=eps2)
+    first, _ = samples.chunk(2, dim=0)
+    assert rel_err(first, gold["sample"]) < 2e-5
+    # generic stepping (any callable) == fused loop, bit for bit
+    gen = diffusion.p_sample_loop(lambda x, t, **kw: model(x, t, **kw), cat_z.shape, cat_z, clip_denoised=False,
+                                  model_kwargs=kwargs, device=DEV, step_noise=eps2)
+    assert torch.equal(gen, samples)
+    # device RNG: the fused loop draws randn_like per step in the reference's order
+    torch.manual_seed(123)
+    a = diffusion.p_sample_loop(model.forward, cat_z.shape, cat_z, clip_denoised=False, model_kwargs=kwargs)
+    torch.manual_seed(123)
+    b = diffusion.p_sample_loop(lambda x, t, **kw: model(x, t, **kw), cat_z.shape, cat_z, clip_denoised=False,
+                                model_kwargs=kwargs)
+    assert torch.equal(a, b)
+
+
+@gpu
+@pytest.mark.parametrize("name", ["N6_L46_B3", "K3_L60_B2"])
+def test_latent_decode_and_ic_to_xyz_like_test_py(name):
+    L, B, seed, vae_type = cases.DECODER_CASES[name]
+    prot, batch, latent, dataname = cases.decoder_inputs(L, B, seed, vae_type)
+    vae = build_vae(vae_type)
+    load_decoder_state(vae, synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED))
+    vae = vae.to(DEV).eval()
+    batch = to_dev(batch)
+    mask = torch.ones(B, L, dtype=torch.bool, device=DEV)
+    # test.py:548 de-normalise, :559 latent_decode, :581-582 ic_to_xyz
+    mean, std = synth.norm_stats(dataname, vae_type)
+    samples = ((latent - mean) / std).to(DEV)
+    lat = get_norm_feature(samples, vae_type, norm_in=False, dataname=dataname)
+    ic, ic_recon = vae.latent_decode(lat, mask, batch)
+    gold = np.load(cases.npz_path(f"g5_decode_{name}"))
+    assert ic is None and ic_recon.shape == (B * L, 13, 3)
+    assert rel_err(ic_recon, gold["ic_recon"]) < 5e-5
+    nres = L + 2
+    xyz = ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, nres, 4), ic_recon.reshape(-1, nres - 2, 13, 3), prot["info"])
+    gx = torch.from_numpy(np.load(cases.npz_path(f"g6_xyz_{name}"))["xyz"])
+    assert float(((xyz.cpu() - gx) ** 2).sum(-1).mean().sqrt()) < 1e-3

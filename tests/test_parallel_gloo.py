@@ -1,0 +1,94 @@
+"""Multi-process path on CPU: world_size 2, gloo backend, 127.0.0.1 rendezvous.  Covers what the
+N > 1 bench/driver does around the (GPU-only) compute: unit sharding, weight-blob broadcast from
+rank 0, and the final ragged all-gather of coordinates."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from codlad_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeWeights:
+    """Stands in for weights.DenoiserWeights on CPU: one flat blob + rebind()."""
+
+    def __init__(self, n, fill):
+        self.blob = type("B", (), {})()
+        self.blob.data = torch.full((n,), float(fill))
+        self.rebinds = 0
+
+    def rebind(self):
+        self.rebinds += 1
+
+
+def _unit_result(u, L):
+    g = torch.Generator().manual_seed(1000 + u)        # per-unit seed: result independent of the sharding
+    return torch.randn(7 * L, 3, generator=g)
+
+
+def _worker(rank, world, port, lengths, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        den, dec = _FakeWeights(1000, rank + 1), _FakeWeights(10, 10 * (rank + 1))
+        parallel.broadcast_weights(den, dec)
+        assert float(den.blob.data.min()) == 1.0 == float(den.blob.data.max())      # rank 0's values everywhere
+        assert float(dec.blob.data[0]) == 10.0 and den.rebinds == dec.rebinds == 1
+        shards = parallel.shard_units([parallel.unit_cost(L) for L in lengths], world)
+        mine = [_unit_result(u, lengths[u]) for u in shards[rank]]
+        gathered = parallel.gather_coordinates(mine, world)
+        assert len(gathered) == world
+        # reassemble in unit order on every rank
+        out = {}
+        for r in range(world):
+            flat, o = gathered[r], 0
+            for u in shards[r]:
+                n = 7 * lengths[u] * 3
+                out[u] = flat[o:o + n].view(-1, 3)
+                o += n
+            assert o == flat.numel()
+        ok = all(torch.equal(out[u], _unit_result(u, lengths[u])) for u in range(len(lengths)))
+        q.put((rank, ok, [len(s) for s in shards]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_broadcast_shard_gather_world2():
+    lengths = [46, 87, 92, 129, 505, 39, 155, 60, 87]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, lengths, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == res[1][2] and sum(res[0][2]) == len(lengths)
+
+
+def test_shard_units_balance_and_coverage():
+    lengths = [39, 46, 87, 92, 129, 155, 155, 200, 505, 505, 60, 61, 300]
+    costs = [parallel.unit_cost(L) for L in lengths]
+    for world in (1, 2, 4, 8):
+        shards = parallel.shard_units(costs, world)
+        assert sorted(u for s in shards for u in s) == list(range(len(lengths)))
+        loads = [sum(costs[u] for u in s) for s in shards]
+        assert max(loads) - min(loads) <= max(costs)          # LPT bound
+    assert parallel.shard_units([], 4) == [[], [], [], []]
+    assert parallel.unit_cost(46) == 46 * 46 and parallel.unit_cost(129) == 129 * 64
