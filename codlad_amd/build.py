@@ -12,7 +12,10 @@ LIB = os.path.join(HERE, "libcodlad_hip.so")
 SOURCES = ["api.hip", "denoiser_kernels.hip", "features_kernels.hip", "decode_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
 # and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
-EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"],
+               # SLP packing of the shuffle-reduction adds blocks their fusion into v_add_f32_dpp;
+               # the packed math that pays (GELU) is written out explicitly in common.h
+               "denoiser_kernels.hip": ["-fno-slp-vectorize"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "codlad_hip.h")]
 
 

@@ -66,15 +66,9 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
             for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = valid ? x.b[bo][r] : 0.f;
-                    v += __shfl_xor(v, 1, 64);
-                    v += __shfl_xor(v, 2, 64);
-                    v += __shfl_xor(v, 4, 64);
-                    v += __shfl_xor(v, 8, 64);
-                    v += __shfl_xor(v, 16, 64);
-                    x.b[bo][r] = v;
+                    x.b[bo][r] = half_wave_sum(valid ? x.b[bo][r] : 0.f);
                 }
-            if (c == 0) {
+            if (c == 31) {
                 if (half) tile_add_row(x, Srow, h);
                 tile_store_row(x, Srow, h);
             }
