@@ -27,12 +27,22 @@ class DecLayer(C.Structure):
                [(n, P) for n in ("b1", "b2", "b3", "b_in", "b_out")]
 
 
+class EncLayerH(C.Structure):
+    _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c")] + \
+               [("Win", P * 4), ("Wout", P * 4)]
+
+
+class DecLayerH(C.Structure):
+    _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W1a", "W1v")] + [("Win", P * 4), ("Wout", P * 4)]
+
+
 class DenoiserWeights(C.Structure):
     _fields_ = [(n, P) for n in ("freqs", "rbf_mu", "t_w0", "t_b0", "t_w2", "t_b2")] + \
                [("ada_w", P * 7), ("ada_b", P * 7)] + \
                [(n, P) for n in ("x_in_w", "x_in_b", "pos_w", "pos_b", "edge_wT", "norm_w", "norm_b",
                                  "We_wT", "We_b", "out_w", "out_b")] + \
-               [("enc", EncLayer * 3), ("dec", DecLayer * 3)]
+               [("enc", EncLayer * 3), ("dec", DecLayer * 3), ("precision", C.c_int),
+                ("enc_h", EncLayerH * 3), ("dec_h", DecLayerH * 3)]
 
 
 class Workspace(C.Structure):

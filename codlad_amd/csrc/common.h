@@ -106,6 +106,175 @@ DEV void gemm128(Tile &acc, const Tile &in, const float *__restrict__ Wpacked, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32-equivalent contraction on the fp16 matrix pipe ("f16x4").
+//
+// v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 vector lanes: measured on MI355X
+// (tools/ubench/coexec.hip) a wave issuing fp32 MFMAs and a partner wave issuing v_fma_f32 take
+// exactly the SUM of their separate times, so bias/GELU/LayerNorm work is never hidden behind an
+// fp32 contraction.  The f16 MFMA (32x32x16, 32 cycles for 16 k) has its own pipe and 16x the rate.
+// Both operands are split into two fp16 halves by round-to-nearest,
+//     x = hi + lo (+ eps),  hi = f16(x),  lo = f16(x - hi),  |eps| <= 2^-22 |x|
+// and all four partial products hi*hi + hi*lo + lo*hi + lo*lo are accumulated in fp32 by the MFMA
+// (fp16 x fp16 products are exact in fp32).  Per 16 k this costs 4 x 32 = 128 matrix-pipe cycles
+// against 8 x 64 = 512 ALU cycles for the fp32 MFMA, and the ALUs stay free for the epilogues.
+//
+// Layout: same chain as above.  k-step ks = 2*b + s consumes registers 8s..8s+7 of input block b;
+// element j of lane half h is feature 32*b + 16*s + 8*(j>>2) + 4*h + (j&3).  A packed weight block
+// (64 KB) is [ks 0..7][bo 0..3][split hi,lo][lane 0..63][8 halves]: one 16-byte read per lane per
+// fragment, lane-linear (conflict-free from LDS, coalesced from L2).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct SplitFrag {
+    f16x8 hi, lo;
+};
+
+// 8 consecutive accumulator registers -> hi/lo fp16 fragments (5 VALU instructions per pair)
+template <int S>
+DEV SplitFrag split_frag(const f32x16 &v) {
+    SplitFrag f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 x = {v[8 * S + j], v[8 * S + j + 1]};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 r = x - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        f.hi[j] = h.x; f.hi[j + 1] = h.y;
+        f.lo[j] = l.x; f.lo[j + 1] = l.y;
+    }
+    return f;
+}
+
+DEV f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+DEV void mfma_f16x4(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
+    // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.hi, acc, 0, 0, 0);
+}
+
+// acc += W(128x128, f16x4-packed block in LDS) @ in.  128 f16 MFMAs in 32 groups (k-step, out
+// block) of four; weight fragments are read from LDS two groups ahead through a register ring.
+//
+// `side(ks)` is called once per k-step with independent fp32 work (GELU / reduction / LayerNorm
+// of ANOTHER tile).  Measured on MI355X (tools/ubench/coexec.hip): VALU instructions placed
+// between the f16 MFMAs of the SAME wave are hidden behind the matrix pipe (32 MFMA + 128 v_fma
+// take the time of the 32 MFMAs), while the same VALU work in the partner wave of the SIMD adds
+// ~55 % of its own time.  So each wave software-pipelines two column tiles and overlaps the
+// epilogue of one with the contraction of the other.
+struct NoSideWork {
+    DEV void operator()(int, int) const {}
+};
+
+template <int N>
+DEV void gelu_pairs(f32x2 (&x)[N]);
+
+// hi/lo fp16 split of register pair P (0..3) of k-step KS into elements 2P, 2P+1 of a fragment.
+// GELU_IN: the tile holds pre-activations and GELU is applied here, on the way into the
+// contraction - the activation of k-step ks+1 then sits between the MFMAs of k-step ks of the
+// SAME tile (no second tile, no extra registers), where the matrix pipe hides it.
+template <bool GELU_IN>
+DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
+    const f32x16 &v = in.b[ks >> 1];
+    const int r = (ks & 1) * 8 + 2 * p;
+    f32x2 x = {v[r], v[r + 1]};
+    if (GELU_IN) {
+        f32x2 t[1] = {x};
+        gelu_pairs<1>(t);
+        x = t[0];
+    }
+    const f16x2 hh = __builtin_convertvector(x, f16x2);
+    const f32x2 rem = x - __builtin_convertvector(hh, f32x2);
+    const f16x2 ll = __builtin_convertvector(rem, f16x2);
+    f.hi[2 * p] = hh.x; f.hi[2 * p + 1] = hh.y;
+    f.lo[2 * p] = ll.x; f.lo[2 * p + 1] = ll.y;
+}
+
+// One group = (k-step ks, out block bo): fragment prefetch for two groups ahead, a quarter of
+// the NEXT k-step's operand split, four MFMAs, and side(ks, bo) - a quarter of the side work of
+// this k-step (one register pair of another tile).  The sched_barrier closes the scheduling
+// region: inside it the compiler interleaves the ~25-35 VALU instructions with the four MFMAs
+// (128 matrix-pipe cycles); across it nothing moves, which keeps register pressure bounded
+// (left alone, hipcc hoists loads and epilogue arithmetic across the whole 128-MFMA block and
+// spills hundreds of registers).
+template <int KS0, int NKS, bool GELU_IN, typename Side>
+DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, Side side) {
+    const u32x4 *w = wl + lane;
+    constexpr int G0 = KS0 * 4, NG = NKS * 4;
+    u32x4 ring[3][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        ring[g][0] = w[((G0 + g) * 2 + 0) * 64];
+        ring[g][1] = w[((G0 + g) * 2 + 1) * 64];
+    }
+    SplitFrag x, xn;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ks = KS0 + (g >> 2), bo = g & 3;
+        if (g + 2 < NG) {
+            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];
+            ring[(g + 2) % 3][1] = w[((G0 + g + 2) * 2 + 1) * 64];
+        }
+        if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
+        mfma_f16x4(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
+        side(ks, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        if (bo == 3) x = xn;
+    }
+}
+
+// acc += W @ act(in): GELU_IN applies GELU to `in` on the fly (see split_pair)
+template <bool GELU_IN>
+DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
+    gemm_h_lds<0, 8, GELU_IN>(acc, in, wl, lane, NoSideWork());
+}
+
+// The same k-step with the weight fragments fetched from global memory (L2-resident) through a
+// buffer descriptor (8 coalesced 1 KiB wave loads per k-step).
+DEV u32x4 weight_frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, frag_index * 1024, 0));
+}
+
+template <int KS0, int NKS, bool GELU_IN, typename Side>
+DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, Side side) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wpacked), 0, 65536, 0x00020000);
+    constexpr int G0 = KS0 * 4, NG = NKS * 4;
+    u32x4 ring[4][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        ring[g][0] = weight_frag_load(rsrc, lane, (G0 + g) * 2 + 0);
+        ring[g][1] = weight_frag_load(rsrc, lane, (G0 + g) * 2 + 1);
+    }
+    SplitFrag x, xn;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ks = KS0 + (g >> 2), bo = g & 3;
+        if (g + 3 < NG) {
+            ring[(g + 3) & 3][0] = weight_frag_load(rsrc, lane, (G0 + g + 3) * 2 + 0);
+            ring[(g + 3) & 3][1] = weight_frag_load(rsrc, lane, (G0 + g + 3) * 2 + 1);
+        }
+        if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
+        mfma_f16x4(acc.b[bo], as_f16x8(ring[g & 3][0]), as_f16x8(ring[g & 3][1]), x);
+        side(ks, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        if (bo == 3) x = xn;
+    }
+}
+
+DEV void gemm128_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
+    gemm_h_glb<0, 8, false>(acc, in, Wpacked, lane, NoSideWork());
+}
+
 // GELU(x) = (0.5 x)(1 + erf(x/sqrt 2)), erf to <= 8.3e-8 absolute (fp32 erf has ulp 6e-8 near 1).
 // Branch-free: with t = min(|x|/sqrt 2, 4),  erfc(t) = exp(-t g(t)),  g a degree-8 minimax fit of
 // -ln(erfc t)/t on [0,4] (coefficients pre-multiplied by -log2 e so one v_exp_f32 finishes it);
@@ -214,6 +383,22 @@ DEV void tile_gelu(Tile &t) {
                 t.b[bo][r + 2 * i + 1] = v[i].y;
             }
         }
+#endif
+}
+
+// GELU of one register pair: pair p (0..3) of k-step slice ks (8 registers) of a tile - the unit
+// of side work attached to one MFMA group.
+DEV void tile_gelu_pair(Tile &t, int ks, int p) {
+    f32x16 &blk = t.b[ks >> 1];
+    const int r = (ks & 1) * 8 + 2 * p;
+#ifdef CODLAD_EXACT_ERF
+    blk[r] = gelu_erf(blk[r]);
+    blk[r + 1] = gelu_erf(blk[r + 1]);
+#else
+    f32x2 v[1] = {f32x2{blk[r], blk[r + 1]}};
+    gelu_pairs<1>(v);
+    blk[r] = v[0].x;
+    blk[r + 1] = v[0].y;
 #endif
 }
 

@@ -24,6 +24,7 @@ struct EdgeArgs {
     float *hE_out;         // edge update only
     const float *P, *Q;    // [n_nodes][128]: own-node term (+bias), neighbour term
     const float *W1, *W2, *W3;
+    const void *W1h, *W2h, *W3h;  // f16x4-packed copies (precision 1)
     const float *b2, *b3;
     const float *mods3;    // edge update: shift3, scale3, gate3 (3 x 128)
     float *S;              // message: [n_nodes][128]
@@ -79,6 +80,103 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
             tile_layernorm(acc, 1e-6f);
             tile_modulate(acc, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);
             if (valid) tile_store_row(acc, a.hE_out + ((size_t)n * 64 + col) * HD, h);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16x4 edge kernels (precision 1).  Persistent 512-thread workgroups, one per CU: the two (three)
+// 64 KB weight blocks of the MLP live in LDS for the whole launch - 128 KB for the message kernel,
+// 160 KB for the edge update (W11e, W12 and the first four k-steps of W13; its last four k-steps
+// stream from L2) - and every wave walks nodes with a grid stride.  The contraction runs on the
+// f16 matrix pipe while the fp32 lanes do the split / bias / GELU / reduction work of the other
+// wave on the SIMD.
+// ---------------------------------------------------------------------------------------------
+#define LDS_BLOCK_U4 4096   // one 64 KB packed block in 16-byte words
+
+// masked sum over the wave half's 32 columns of register pair p of k-step slice ks
+DEV void tile_colsum_pair(Tile &t, int ks, int p, bool valid) {
+    f32x16 &blk = t.b[ks >> 1];
+    const int r = (ks & 1) * 8 + 2 * p;
+    blk[r] = half_wave_sum(valid ? blk[r] : 0.f);
+    blk[r + 1] = half_wave_sum(valid ? blk[r + 1] : 0.f);
+}
+
+DEV void tile_colsum(Tile &t, bool valid) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) tile_colsum_pair(t, ks, p, valid);
+}
+
+// edge-update epilogue of one 32-column tile: h_E <- gate3 * mod3(LN(h_E + message))
+DEV void edge_epilogue(Tile &acc, const float *row_in, float *row_out, const float *mods3, bool valid, int h) {
+    tile_add_row(acc, row_in, h);
+    tile_layernorm(acc, 1e-6f);
+    tile_modulate(acc, mods3, mods3 + HD, mods3 + 2 * HD, h);
+    if (valid) tile_store_row(acc, row_out, h);
+}
+
+template <bool EDGE_UPDATE, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArgs a) {
+    extern __shared__ __align__(16) u32x4 wl[];
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
+        const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
+        for (int i = tid; i < LDS_BLOCK_U4; i += NT) {
+            wl[i] = g1[i];
+            wl[LDS_BLOCK_U4 + i] = g2[i];
+        }
+        if (EDGE_UPDATE) {
+            const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.W3h);
+            for (int i = tid; i < LDS_BLOCK_U4 / 2; i += NT) wl[2 * LDS_BLOCK_U4 + i] = g3[i];
+        }
+    }
+    __syncthreads();
+    const u32x4 *w1 = wl, *w2 = wl + LDS_BLOCK_U4, *w3 = wl + 2 * LDS_BLOCK_U4;
+    const int h = lane >> 5, c = lane & 31;
+    for (int n = blockIdx.x * NWAVES + wave; n < a.n_nodes; n += gridDim.x * NWAVES) {
+        const int4 info = a.node_info[n];
+        const int src = info.x, base = info.y, K = info.z;
+        const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * (64 * HD);
+        const float *Prow = a.P + (size_t)n * HD;
+        float *out_rows = EDGE_UPDATE ? a.hE_out + (size_t)n * (64 * HD) : nullptr;
+        const bool two = K > 32;                      // wave-uniform
+        const bool validA = c < K, validB = 32 + c < K;
+        const int colA = validA ? c : 0, colB = validB ? 32 + c : 0;
+        const int jA = a.E_idx[(size_t)src * 64 + colA], jB = a.E_idx[(size_t)src * 64 + colB];
+
+        Tile sum;   // message: column sums of the node's first half
+        for (int half = 0; half < 2; ++half) {
+            if (32 * half >= K) break;
+            const bool valid = half ? validB : validA;
+            const int colc = half ? colB : colA, col = 32 * half + c;
+            const int j = half ? jB : jA;
+            Tile x, acc;
+            tile_load_row(x, rows + (size_t)colc * HD, h);
+            tile_load_row(acc, Prow, h);
+            tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
+            gemm128_h_lds<false>(acc, x, w1, lane);          // layer 1
+            tile_load_row(x, a.b2, h);
+            gemm128_h_lds<true>(x, acc, w2, lane);           // layer 2 on GELU(layer 1), GELU under the MFMAs
+            if (!EDGE_UPDATE) {
+                tile_gelu(x);
+                tile_colsum(x, valid);
+                if (half == 0) {
+                    sum = x;
+                } else {
+#pragma unroll
+                    for (int bo = 0; bo < 4; ++bo) x.b[bo] += sum.b[bo];
+                }
+                if (c == 31 && (half == 1 || !two)) tile_store_row(x, a.S + (size_t)n * HD, h);
+            } else {
+                tile_load_row(acc, a.b3, h);
+                gemm_h_lds<0, 4, true>(acc, x, w3, lane, NoSideWork());      // layer 3 on GELU(layer 2)
+                gemm_h_glb<4, 4, true>(acc, x, a.W3h, lane, NoSideWork());
+                edge_epilogue(acc, rows + (size_t)colc * HD, out_rows + (size_t)col * HD, a.mods3, valid, h);
+            }
         }
     }
 }
@@ -311,7 +409,38 @@ static inline int mods_offset(int head) {  // enc0..2, dec0..2, final
     return head < 3 ? head * 9 * HD : (head < 6 ? 27 * HD + (head - 3) * 6 * HD : 45 * HD);
 }
 
-static void launch_edge(bool update, const EdgeArgs &ea, hipStream_t st) {
+static int g_num_cu = 0;
+
+static int num_cu() {
+    if (!g_num_cu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_num_cu = n;
+    }
+    return g_num_cu;
+}
+
+static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st) {
+    if (precision == 1) {
+        static bool attr_set = false;
+        const size_t lds_msg = 2 * 65536, lds_upd = 2 * 65536 + 32768;
+        constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msg);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(edge_kernel_h<true, UPD_WAVES>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd);
+            attr_set = true;
+        }
+        const int nw = update ? UPD_WAVES : MSG_WAVES;
+        const int groups = (ea.n_nodes + nw - 1) / nw;
+        dim3 grid(groups < num_cu() ? groups : num_cu()), block(nw * 64);
+        if (update) hipLaunchKernelGGL((edge_kernel_h<true, UPD_WAVES>), grid, block, lds_upd, st, ea);
+        else hipLaunchKernelGGL((edge_kernel_h<false, MSG_WAVES>), grid, block, lds_msg, st, ea);
+        return;
+    }
     dim3 grid((ea.n_nodes + 3) / 4), block(256);
     if (update) hipLaunchKernelGGL(edge_kernel<true>, grid, block, 0, st, ea);
     else hipLaunchKernelGGL(edge_kernel<false>, grid, block, 0, st, ea);
@@ -348,7 +477,8 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         ea.node_info = ni; ea.E_idx = E_idx; ea.n_nodes = n_nodes;
         ea.hE_in = l == 0 ? h_E0 : ws->hE; ea.in_by_src = l == 0;
         ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
-        launch_edge(false, ea, st);
+        ea.W1h = w->enc_h[l].W1e; ea.W2h = w->enc_h[l].W2;
+        launch_edge(false, ea, w->precision, st);
 
         NodeArgs na = {};
         na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
@@ -375,7 +505,8 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         eu.hE_in = l == 0 ? h_E0 : ws->hE; eu.in_by_src = l == 0; eu.hE_out = ws->hE;
         eu.P = PQ2; eu.Q = PQ3; eu.W1 = L.W11e; eu.W2 = L.W12; eu.W3 = L.W13;
         eu.b2 = L.b12; eu.b3 = L.b13; eu.mods3 = m + 6 * HD;
-        launch_edge(true, eu, st);
+        eu.W1h = w->enc_h[l].W11e; eu.W2h = w->enc_h[l].W12; eu.W3h = w->enc_h[l].W13;
+        launch_edge(true, eu, w->precision, st);
     }
     for (int l = 0; l < 3; ++l) {
         const codlad_dec_layer &L = w->dec[l];
@@ -383,7 +514,8 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         ea.node_info = ni; ea.E_idx = E_idx; ea.n_nodes = n_nodes;
         ea.hE_in = ws->hE; ea.in_by_src = 0;
         ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
-        launch_edge(false, ea, st);
+        ea.W1h = w->dec_h[l].W1e; ea.W2h = w->dec_h[l].W2;
+        launch_edge(false, ea, w->precision, st);
 
         NodeArgs na = {};
         na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
@@ -476,12 +608,14 @@ extern "C" int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const 
     ea.hE_in = h_E0; ea.in_by_src = 1;
     if (which == 0) {
         ea.P = ws->PQ; ea.Q = ws->PQ + NS; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
+        ea.W1h = w->enc_h[0].W1e; ea.W2h = w->enc_h[0].W2;
     } else {
         ea.hE_out = ws->hE; ea.P = ws->PQ + 2 * NS; ea.Q = ws->PQ + 3 * NS;
         ea.W1 = L.W11e; ea.W2 = L.W12; ea.W3 = L.W13; ea.b2 = L.b12; ea.b3 = L.b13;
         ea.mods3 = mods_t + 6 * HD;
+        ea.W1h = w->enc_h[0].W11e; ea.W2h = w->enc_h[0].W12; ea.W3h = w->enc_h[0].W13;
     }
-    launch_edge(which == 1, ea, (hipStream_t)stream);
+    launch_edge(which == 1, ea, w->precision, (hipStream_t)stream);
     return codlad_check_launch("codlad_bench_edge_launch");
 }
 

@@ -84,12 +84,12 @@ class Job:
 class Denoiser:
     """mpnn_diffusion on the GPU."""
 
-    def __init__(self, state_dict, device):
+    def __init__(self, state_dict, device, precision="f16x4"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")
         self.lib = _lib.lib()
-        self.weights = DenoiserWeights(state_dict, self.device)
+        self.weights = DenoiserWeights(state_dict, self.device, precision)
         self._mods_cache = {}
 
     # -- step-invariant part -------------------------------------------------------------------

@@ -40,6 +40,30 @@ def pack_block(w, scale=1.0):
     return out * scale if scale != 1.0 else out.clone()
 
 
+def _pack_index_h():
+    """(row, col) of the source block for every element of the f16x4 order
+    [k-step][out block][split][lane][8 halves] (split handled by the caller)."""
+    ks, bo, lane, j = np.meshgrid(np.arange(8), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
+    b, s_, h = ks >> 1, ks & 1, lane >> 5
+    rows = 32 * bo + (lane & 31)
+    cols = 32 * b + 16 * s_ + 8 * (j >> 2) + 4 * h + (j & 3)
+    return torch.from_numpy(rows), torch.from_numpy(cols)          # [8,4,64,8]
+
+
+_ROWS_H, _COLS_H = _pack_index_h()
+
+
+def pack_block_h(w, scale=1.0):
+    """[128,128] block -> hi/lo fp16 split in MFMA f16 operand order, returned as 16384 float32
+    words (bit container for 32768 halves = 64 KB)."""
+    assert tuple(w.shape) == (H, H)
+    g = (w.detach().float().cpu() * scale)[_ROWS_H, _COLS_H]           # [ks, bo, lane, 8] fp32
+    hi = g.to(torch.float16)                                           # round to nearest even
+    lo = (g - hi.float()).to(torch.float16)
+    packed = torch.stack([hi, lo], dim=2).contiguous()                 # [ks, bo, split, lane, 8]
+    return packed.view(-1).view(torch.float32).clone()
+
+
 def strip_module_prefix(sd):
     """Checkpoints saved from a DDP-wrapped model carry `module.` (reference test.py:279-286)."""
     if all(k.startswith("module.") for k in sd):
@@ -106,6 +130,39 @@ def denoiser_tensors(sd):
     return t
 
 
+def denoiser_tensors_h(sd):
+    """f16x4 copies of every 128x128 block, same names with an `h.` prefix."""
+    sd = strip_module_prefix(sd)
+    g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
+    t = OrderedDict()
+    for l in range(3):
+        p = f"encoder_layers.{l}"
+        W1, W11 = g(f"{p}.W1.weight"), g(f"{p}.W11.weight")
+        e = f"h.enc{l}."
+        t[e + "W1e"] = pack_block_h(W1[:, 128:256]); t[e + "W2"] = pack_block_h(g(f"{p}.W2.weight"))
+        t[e + "W3"] = pack_block_h(g(f"{p}.W3.weight"))
+        t[e + "W11e"] = pack_block_h(W11[:, 128:256]); t[e + "W12"] = pack_block_h(g(f"{p}.W12.weight"))
+        t[e + "W13"] = pack_block_h(g(f"{p}.W13.weight"))
+        t[e + "W1a"] = pack_block_h(W1[:, 0:128]); t[e + "W1c"] = pack_block_h(W1[:, 256:384])
+        t[e + "W11a"] = pack_block_h(W11[:, 0:128]); t[e + "W11c"] = pack_block_h(W11[:, 256:384])
+        Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
+        for c in range(4):
+            t[e + f"Win{c}"] = pack_block_h(Win[128 * c:128 * c + 128, :])
+            t[e + f"Wout{c}"] = pack_block_h(Wout[:, 128 * c:128 * c + 128])
+    for l in range(3):
+        p = f"decoder_layers.{l}"
+        W1 = g(f"{p}.W1.weight")
+        d = f"h.dec{l}."
+        t[d + "W1e"] = pack_block_h(W1[:, 128:256], 2.0)
+        t[d + "W2"] = pack_block_h(g(f"{p}.W2.weight")); t[d + "W3"] = pack_block_h(g(f"{p}.W3.weight"))
+        t[d + "W1a"] = pack_block_h(W1[:, 0:128]); t[d + "W1v"] = pack_block_h(W1[:, 384:512])
+        Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
+        for c in range(4):
+            t[d + f"Win{c}"] = pack_block_h(Win[128 * c:128 * c + 128, :])
+            t[d + f"Wout{c}"] = pack_block_h(Wout[:, 128 * c:128 * c + 128])
+    return t
+
+
 def decoder_tensors(sd):
     """IC decoder + map_out + codebook (reference models/vae_model.py:318-503, 704-706)."""
     g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
@@ -167,9 +224,15 @@ class Blob:
         return self.data[o:o + n].view(shape)
 
 
+PRECISIONS = {"f32": 0, "f16x4": 1}
+
+
 class DenoiserWeights:
-    def __init__(self, state_dict, device):
-        self.blob = Blob(denoiser_tensors(state_dict), device)
+    def __init__(self, state_dict, device, precision="f16x4"):
+        tensors = denoiser_tensors(state_dict)
+        tensors.update(denoiser_tensors_h(state_dict))
+        self.blob = Blob(tensors, device)
+        self.precision = precision
         self.struct = self._fill()
 
     def _fill(self):
@@ -190,7 +253,20 @@ class DenoiserWeights:
             for c in range(4):
                 e.Win[c], e.Wout[c] = p(f"enc{l}.Win{c}"), p(f"enc{l}.Wout{c}")
                 d.Win[c], d.Wout[c] = p(f"dec{l}.Win{c}"), p(f"dec{l}.Wout{c}")
+            eh, dh = w.enc_h[l], w.dec_h[l]
+            for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c"):
+                setattr(eh, n, p(f"h.enc{l}.{n}"))
+            for n in ("W1e", "W2", "W3", "W1a", "W1v"):
+                setattr(dh, n, p(f"h.dec{l}.{n}"))
+            for c in range(4):
+                eh.Win[c], eh.Wout[c] = p(f"h.enc{l}.Win{c}"), p(f"h.enc{l}.Wout{c}")
+                dh.Win[c], dh.Wout[c] = p(f"h.dec{l}.Win{c}"), p(f"h.dec{l}.Wout{c}")
+        w.precision = PRECISIONS[self.precision]
         return w
+
+    def set_precision(self, precision):
+        self.precision = precision
+        self.struct.precision = PRECISIONS[precision]
 
     def rebind(self):
         """Re-derive the pointers after the blob storage changed (e.g. after a broadcast)."""

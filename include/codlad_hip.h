@@ -67,6 +67,19 @@ typedef struct {
     const float *b1, *b2, *b3, *b_in, *b_out;
 } codlad_dec_layer;
 
+/* f16x4 copies of the 128x128 blocks: each weight split into hi + lo fp16 halves, 64 KB per block in
+ * the order [k-step 0..7][out block 0..3][hi,lo][lane 0..63][8 halves] (codlad_amd/csrc/common.h).
+ * Used when codlad_denoiser_weights.precision == 1. */
+typedef struct {
+    const void *W1e, *W2, *W3, *W11e, *W12, *W13, *W1a, *W1c, *W11a, *W11c;
+    const void *Win[4], *Wout[4];
+} codlad_enc_layer_h;
+
+typedef struct {
+    const void *W1e, *W2, *W3, *W1a, *W1v;
+    const void *Win[4], *Wout[4];
+} codlad_dec_layer_h;
+
 /* Replaces the parameters of reference models/latent_model.py:119-148 (ProteinMPNN_diffusion_new). */
 typedef struct {
     const float *freqs;                /* [128] exp(-ln(1e4) k/128)  (latent_model.py:62-64)   */
@@ -82,6 +95,13 @@ typedef struct {
     const float *out_w, *out_b;        /* W_out.linear [6][128], [6]                           */
     codlad_enc_layer enc[3];
     codlad_dec_layer dec[3];
+    /* 0: contractions on v_mfma_f32_32x32x2_f32 (exact fp32 products);
+     * 1: f16x4 - operands split into two fp16 halves, four f16 MFMAs per product, fp32 accumulate
+     *    (operand representation error <= 2^-22, i.e. fp32-equivalent; 4x fewer matrix cycles and
+     *    they overlap with the fp32 epilogue work). */
+    int precision;
+    codlad_enc_layer_h enc_h[3];
+    codlad_dec_layer_h dec_h[3];
 } codlad_denoiser_weights;
 
 /* Row 4: CA_ProteinFeatures.forward + W_e

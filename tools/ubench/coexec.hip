@@ -46,6 +46,70 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float *out) {
             }
         }
         out[blockIdx.x * 512 + threadIdx.x] = x0.x + x1.y + x2.x + x3.y + x4.x + x5.y + x6.x + x7.y;
+    } else if ((mode == 6 || mode == 7 || mode == 8 || mode == 9 || mode == 10) && mf) {
+        if (mode == 9) __builtin_amdgcn_s_setprio(3);
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        f16x8 ha, hb;
+        for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(a + i); hb[i] = (_Float16)(b + i); }
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        float x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {   // 32 f16 MFMAs per iteration = 1024 matrix cycles
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c0, 0, 0, 0);
+                if (mode == 8) { x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a); }
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c1, 0, 0, 0);
+                if (mode == 8) { x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a); }
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c2, 0, 0, 0);
+                if (mode == 8) { x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a); }
+                c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c3, 0, 0, 0);
+                if (mode == 8) { x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + x0 + x1 + x2 + x3;
+    } else if ((mode == 7 || mode == 9 || mode == 10) && !mf) {
+        if (mode == 10) __builtin_amdgcn_s_setprio(3);
+        float x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3, x4 = a + 4, x5 = a + 5, x6 = a + 6, x7 = a + 7;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a);
+                x4 = fmaf(x4, b, a); x5 = fmaf(x5, b, a); x6 = fmaf(x6, b, a); x7 = fmaf(x7, b, a);
+            }
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    } else if (mode >= 11 && mode <= 14 && mf) {
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        f16x8 ha, hb;
+        for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(a + i); hb[i] = (_Float16)(b + i); }
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+        float x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3, x4 = a + 4, x5 = a + 5, x6 = a + 6, x7 = a + 7;
+        f32x2 p0 = {a, a}, p1 = {a + 1, a}, p2 = {a + 2, a}, p3 = {a + 3, a};
+        const f32x2 bb = {b, b}, aa = {a, a};
+#define FILL()                                                                                         \
+    if (mode == 11) { x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a);  \
+                      x4 = fmaf(x4, b, a); x5 = fmaf(x5, b, a); x6 = fmaf(x6, b, a); x7 = fmaf(x7, b, a); } \
+    if (mode == 12) { p0 = p0 * bb + aa; p1 = p1 * bb + aa; p2 = p2 * bb + aa; p3 = p3 * bb + aa; }      \
+    if (mode == 13) { x0 = __builtin_amdgcn_exp2f(x0); x1 = __builtin_amdgcn_exp2f(x1); }               \
+    if (mode == 14) { x0 = fmaf(x0, b, a); x1 = fmaf(x1, b, a); x2 = fmaf(x2, b, a); x3 = fmaf(x3, b, a);  \
+                      x4 = fmaf(x4, b, a); x5 = fmaf(x5, b, a); }
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c0, 0, 0, 0);
+                FILL()
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c1, 0, 0, 0);
+                FILL()
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c2, 0, 0, 0);
+                FILL()
+                c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c3, 0, 0, 0);
+                FILL()
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 +
+                                              p0.x + p1.y + p2.x + p3.y;
     } else if (mode == 5 && mf) {
         f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
         float x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
@@ -75,8 +139,12 @@ int main() {
     const int iters = 2000;
     const char *names[] = {"MFMA only (16/iter)", "v_fma only (256/iter)", "MFMA + v_fma partner waves",
                            "v_pk_fma only (256/iter)", "MFMA + v_pk_fma partner waves",
-                           "one wave: 16 MFMA + 64 v_fma interleaved"};
-    for (int mode = 0; mode < 6; ++mode) {
+                           "one wave: 16 MFMA + 64 v_fma interleaved", "f16 MFMA only (32/iter)",
+                           "f16 MFMA + v_fma(256/iter) partner waves", "one wave: 32 f16 MFMA + 128 v_fma interleaved",
+                           "f16 MFMA (prio 3) + v_fma partner", "f16 MFMA + v_fma (prio 3) partner",
+                           "one wave: 32 f16 MFMA + 8 v_fma per gap", "one wave: 32 f16 MFMA + 4 v_pk_fma per gap",
+                           "one wave: 32 f16 MFMA + 2 v_exp per gap", "one wave: 32 f16 MFMA + 6 v_fma per gap"};
+    for (int mode = 0; mode < 15; ++mode) {
         hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, 10, out);
         hipDeviceSynchronize();
         hipEventRecord(e0);
