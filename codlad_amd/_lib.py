@@ -63,6 +63,7 @@ class DecoderWeights(C.Structure):
 _SIGS = {
     "codlad_abi_version": (C.c_int, []),
     "codlad_last_error": (C.c_char_p, []),
+    "codlad_struct_sizes": (None, [C.POINTER(C.c_int)]),
     "codlad_pack_block_host": (None, [P, C.c_int, C.c_float, P]),
     "codlad_features_prepass": (C.c_int, [C.POINTER(DenoiserWeights), P, P, C.c_int, C.c_int, P, P, P]),
     "codlad_step_mods": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P]),

@@ -3,6 +3,7 @@
 #include "../../include/codlad_hip.h"
 
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 
 static thread_local char g_err[512] = "";
@@ -26,6 +27,14 @@ int codlad_check_launch(const char *what) {
 extern "C" int codlad_abi_version(void) { return CODLAD_ABI_VERSION; }
 
 extern "C" const char *codlad_last_error(void) { return g_err; }
+
+extern "C" void codlad_struct_sizes(int *out5) {
+    out5[0] = (int)sizeof(codlad_denoiser_weights);
+    out5[1] = (int)sizeof(codlad_decoder_weights);
+    out5[2] = (int)sizeof(codlad_workspace);
+    out5[3] = (int)offsetof(codlad_denoiser_weights, precision);
+    out5[4] = (int)offsetof(codlad_denoiser_weights, enc_h);
+}
 
 extern "C" void codlad_pack_block_host(const float *src, int ld, float scale, float *dst) {
     for (int b = 0; b < 4; ++b)

@@ -206,6 +206,8 @@ struct NodeArgs {
     const float *hVenc_in;
     float *hVenc_out;                  // if set: also store the new h_V here (h_Venc := h_V)
     int venc_is_self;                  // h_Venc == new h_V (first decoder layer's Q)
+    // precision 1: f16x4 copies of the blocks in execution order: [W3, Win0, Wout0, .., Wout3,] proj0..
+    const void *blk_h[13];
 };
 
 template <bool MODE_UPD>
@@ -279,6 +281,125 @@ __global__ __launch_bounds__(64, 1) void node_kernel(NodeArgs a) {
         else tile_zero(out);
         if (fl & 2) tile_add_row(out, a.TS + (size_t)info.w * HD, h);
         gemm128(out, in, a.proj_w[p], lane);
+        if (valid) tile_store_row(out, a.proj_out[p] + (size_t)node * HD, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16x4 node kernel (precision 1).  A workgroup of NW waves owns NW 32-node tiles; the up to 13
+// weight blocks of the node update are streamed through a 2 x 64 KB LDS double buffer: block i+1
+// is fetched from L2 into registers before the waves contract with block i and written to the
+// other buffer after it, one barrier per block.  Every wave of the chip reads each block from L2
+// once per workgroup instead of once per tile.
+// ---------------------------------------------------------------------------------------------
+template <bool MODE_UPD, int NW>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs a) {
+    extern __shared__ __align__(16) u32x4 wl[];
+    constexpr int NT = NW * 64;
+    constexpr int PER_T = LDS_BLOCK_U4 / NT;              // 16-byte words per thread per block
+    static_assert(LDS_BLOCK_U4 % NT == 0, "block must divide evenly over the workgroup");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int node = (blockIdx.x * NW + wave) * 32 + c;
+    const bool valid = node < a.n_nodes;
+    const int nc = valid ? node : a.n_nodes - 1;
+    const int4 info = a.node_info[nc];
+    const int n_blk = (MODE_UPD ? 9 : 0) + a.n_proj;
+
+    u32x4 stage[PER_T];
+    int cur = 0;                                          // index of the block resident in wl[(cur&1)]
+    auto fetch = [&](int i) {                             // global -> registers
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(a.blk_h[i]);
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) stage[q] = g[q * NT + tid];
+    };
+    auto commit = [&](int i) {                            // registers -> LDS buffer (i & 1)
+        u32x4 *dst = wl + (i & 1) * LDS_BLOCK_U4;
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) dst[q * NT + tid] = stage[q];
+    };
+    // contraction with the current block, then rotate the double buffer
+    auto apply = [&](Tile &acc, const Tile &in, bool gelu_in) {
+        const bool more = cur + 1 < n_blk;
+        if (more) fetch(cur + 1);
+        const u32x4 *w = wl + (cur & 1) * LDS_BLOCK_U4;
+        if (gelu_in) gemm128_h_lds<true>(acc, in, w, lane);
+        else gemm128_h_lds<false>(acc, in, w, lane);
+        if (more) commit(cur + 1);
+        __syncthreads();
+        ++cur;
+    };
+    if (n_blk > 0) {
+        fetch(0);
+        commit(0);
+    }
+    __syncthreads();
+
+    Tile v;
+    if (!MODE_UPD) {
+        const float x0 = a.x[nc * 3 + 0], x1 = a.x[nc * 3 + 1], x2 = a.x[nc * 3 + 2];
+        tile_load_row(v, a.x_in_b, h);
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float *wr = a.x_in_w + f * 3;
+                v.b[bo][r] += fmaf(x2, wr[2], fmaf(x1, wr[1], x0 * wr[0]));
+            }
+    } else {
+        Tile s, t;
+        tile_load_row(s, a.S + (size_t)nc * HD, h);
+        tile_load_row(t, a.b3, h);
+        // S is a sum over up to 64 neighbours and the only operand of the path that is not
+        // normalised: contract W3 with S/64 (exact power-of-two scaling, undone below) so that the
+        // fp16 halves keep 64x more headroom before 65504.
+        const float kf = (float)info.z * 0.015625f;
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) {
+            t.b[bo] *= kf;
+            s.b[bo] *= 0.015625f;
+        }
+        apply(t, s, false);                                                   // W3 @ S
+        tile_load_row(v, a.hV + (size_t)nc * HD, h);
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v.b[bo][r] += (t.b[bo][r] * 64.0f) / 30.0f;
+        tile_layernorm(v, 1e-6f);
+        tile_modulate(v, a.mods, a.mods + HD, a.mods + 2 * HD, h);
+        tile_load_row(t, a.b_out, h);
+#pragma unroll 1
+        for (int ch = 0; ch < 4; ++ch) {
+            tile_load_row(s, a.b_in + ch * HD, h);
+            apply(s, v, false);                                               // W_in chunk
+            apply(t, s, true);                                                // W_out chunk on GELU(hidden)
+        }
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) v.b[bo] += t.b[bo];
+        tile_layernorm(v, 1e-6f);
+        tile_modulate(v, a.mods + 3 * HD, a.mods + 4 * HD, a.mods + 5 * HD, h);
+    }
+    if (valid) {
+        tile_store_row(v, a.hV + (size_t)node * HD, h);
+        if (a.hVenc_out) tile_store_row(v, a.hVenc_out + (size_t)node * HD, h);
+    }
+#pragma unroll 1
+    for (int p = 0; p < a.n_proj; ++p) {
+        Tile in = v, out;
+        const int fl = a.proj_flags[p];
+        if (fl & 1) {
+            if (a.venc_is_self) {
+#pragma unroll
+                for (int bo = 0; bo < 4; ++bo) in.b[bo] += v.b[bo];
+            } else {
+                tile_add_row(in, a.hVenc_in + (size_t)nc * HD, h);
+            }
+        }
+        if (a.proj_b[p]) tile_load_row(out, a.proj_b[p], h);
+        else tile_zero(out);
+        if (fl & 2) tile_add_row(out, a.TS + (size_t)info.w * HD, h);
+        apply(out, in, false);
         if (valid) tile_store_row(out, a.proj_out[p] + (size_t)node * HD, h);
     }
 }
@@ -446,7 +567,23 @@ static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStrea
     else hipLaunchKernelGGL(edge_kernel<false>, grid, block, 0, st, ea);
 }
 
-static void launch_node(bool upd, const NodeArgs &na, hipStream_t st) {
+static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t st) {
+    if (precision == 1) {
+        constexpr int NW = 4;
+        static bool attr_set = false;
+        const size_t lds = 2 * 65536;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<true, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<false, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        dim3 grid((na.n_nodes + 32 * NW - 1) / (32 * NW)), block(NW * 64);
+        if (upd) hipLaunchKernelGGL((node_kernel_h<true, NW>), grid, block, lds, st, na);
+        else hipLaunchKernelGGL((node_kernel_h<false, NW>), grid, block, lds, st, na);
+        return;
+    }
     dim3 grid((na.n_nodes + 31) / 32), block(64);
     if (upd) hipLaunchKernelGGL(node_kernel<true>, grid, block, 0, st, na);
     else hipLaunchKernelGGL(node_kernel<false>, grid, block, 0, st, na);
@@ -468,7 +605,8 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         na.n_proj = 2;
         na.proj_w[0] = w->enc[0].W1a; na.proj_b[0] = w->enc[0].b1; na.proj_out[0] = PQ0;
         na.proj_w[1] = w->enc[0].W1c; na.proj_b[1] = nullptr;      na.proj_out[1] = PQ1;
-        launch_node(false, na, st);
+        na.blk_h[0] = w->enc_h[0].W1a; na.blk_h[1] = w->enc_h[0].W1c;
+        launch_node(false, na, w->precision, st);
     }
     for (int l = 0; l < 3; ++l) {
         const codlad_enc_layer &L = w->enc[l];
@@ -498,7 +636,16 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
             na.proj_flags[3] = 3; na.TS = w->dec[0].TS;
             na.hVenc_out = ws->hVenc; na.venc_is_self = 1;
         }
-        launch_node(true, na, st);
+        {
+            const codlad_enc_layer_h &Lh = w->enc_h[l];
+            int k = 0;
+            na.blk_h[k++] = Lh.W3;
+            for (int c = 0; c < 4; ++c) { na.blk_h[k++] = Lh.Win[c]; na.blk_h[k++] = Lh.Wout[c]; }
+            na.blk_h[k++] = Lh.W11a; na.blk_h[k++] = Lh.W11c;
+            if (l < 2) { na.blk_h[k++] = w->enc_h[l + 1].W1a; na.blk_h[k++] = w->enc_h[l + 1].W1c; }
+            else { na.blk_h[k++] = w->dec_h[0].W1a; na.blk_h[k++] = w->dec_h[0].W1v; }
+        }
+        launch_node(true, na, w->precision, st);
 
         EdgeArgs eu = {};
         eu.node_info = ni; eu.E_idx = E_idx; eu.n_nodes = n_nodes;
@@ -528,7 +675,14 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
             na.proj_w[1] = w->dec[l + 1].W1v; na.proj_b[1] = nullptr;          na.proj_out[1] = PQ1;
             na.proj_flags[1] = 3; na.TS = w->dec[l + 1].TS; na.hVenc_in = ws->hVenc;
         }
-        launch_node(true, na, st);
+        {
+            const codlad_dec_layer_h &Lh = w->dec_h[l];
+            int k = 0;
+            na.blk_h[k++] = Lh.W3;
+            for (int c = 0; c < 4; ++c) { na.blk_h[k++] = Lh.Win[c]; na.blk_h[k++] = Lh.Wout[c]; }
+            if (l < 2) { na.blk_h[k++] = w->dec_h[l + 1].W1a; na.blk_h[k++] = w->dec_h[l + 1].W1v; }
+        }
+        launch_node(true, na, w->precision, st);
     }
 }
 

@@ -41,6 +41,10 @@ extern "C" {
 
 int codlad_abi_version(void);
 const char *codlad_last_error(void);
+/* sizeof(codlad_denoiser_weights), sizeof(codlad_decoder_weights), sizeof(codlad_workspace),
+ * offsetof(codlad_denoiser_weights, precision), offsetof(.., enc_h): lets a binding verify its
+ * struct mirrors. */
+void codlad_struct_sizes(int *out5);
 
 /* 128x128 weight block -> MFMA A-operand order (host helper; src/dst are HOST pointers).
  * dst[(16*b + r)*256 + lane*4 + bo] = src[(32*bo + (lane&31))*ld + 32*b + (r&3) + 8*(r>>2) + 4*(lane>>5)]

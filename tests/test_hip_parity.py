@@ -30,9 +30,11 @@ def sd():
     return synth.denoiser_state_dict(cases.WEIGHT_SEED)
 
 
-@pytest.fixture(scope="module")
-def den(sd):
-    return Denoiser(sd, DEV)
+@pytest.fixture(scope="module", params=["f16x4", "f32"])
+def den(sd, request):
+    """Both contraction modes of the library: f16x4 (default: fp16 hi/lo split operands on the f16
+    matrix pipe, fp32 accumulate) and f32 (v_mfma_f32_32x32x2_f32)."""
+    return Denoiser(sd, DEV, precision=request.param)
 
 
 def tables(T):
@@ -193,6 +195,24 @@ def test_stepwise_equals_fused_loop(den, sd):
         x = den.ddpm_update(x, out, eps[k].reshape(-1, 3).to(DEV), tb, i)
     fused = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tb)
     assert torch.equal(x, fused)
+
+
+def test_f16x4_agrees_with_f32_mfma_and_survives_large_latents(sd):
+    """The two contraction modes agree to fp32 rounding level, also when the latent is far outside
+    the trained range (|x| ~ 3000, as late steps of an untrained sampler produce): the only
+    un-normalised operand, the neighbour sum S, is contracted with a power-of-two pre-scale so its
+    fp16 halves do not overflow."""
+    L, B, seed = cases.DENOISER_CASES["L87_B2"]
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    outs = {}
+    for prec in ("f32", "f16x4"):
+        d = Denoiser(sd, DEV, precision=prec)
+        st = structures_of(d, prot)
+        job = d.make_job(st, list(range(B)))
+        outs[prec] = [d.forward(job, (x * s).reshape(-1, 3).to(DEV), 500).cpu() for s in (1.0, 30.0, 3000.0)]
+    for a, b in zip(outs["f32"], outs["f16x4"]):
+        assert bool(torch.isfinite(b).all())
+        assert rel_err(b, a) < 5e-6
 
 
 def test_deterministic_replay(den, sd):

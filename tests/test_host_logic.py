@@ -29,11 +29,15 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # pointer counts of the ctypes mirrors = those of the C structs (all members are pointers)
-    assert C.sizeof(_lib.EncLayer) == 26 * 8
-    assert C.sizeof(_lib.DecLayer) == 19 * 8
-    assert C.sizeof(_lib.DenoiserWeights) == (6 + 14 + 11) * 8 + 3 * 26 * 8 + 3 * 19 * 8
-    assert C.sizeof(_lib.Workspace) == 5 * 8
+    # the ctypes mirrors must have exactly the C structs' sizes and field offsets
+    out = (C.c_int * 5)()
+    _lib.lib().codlad_struct_sizes(out)
+    assert C.sizeof(_lib.DenoiserWeights) == out[0]
+    assert C.sizeof(_lib.DecoderWeights) == out[1]
+    assert C.sizeof(_lib.Workspace) == out[2]
+    assert _lib.DenoiserWeights.precision.offset == out[3]
+    assert _lib.DenoiserWeights.enc_h.offset == out[4]
+    assert C.sizeof(_lib.EncLayer) == 26 * 8 and C.sizeof(_lib.DecLayer) == 19 * 8
 
 
 def test_argument_errors_are_reported_not_crashed():
@@ -56,6 +60,26 @@ def test_pack_block_matches_library_packer():
     assert np.array_equal(mine.numpy(), dst)
     # every source element appears exactly once
     assert np.array_equal(np.sort(dst), np.sort(2.0 * blk.numpy().reshape(-1)))
+
+
+def test_f16x4_block_packing():
+    """hi + lo fp16 halves reproduce the fp32 weight to <= 2^-22 relative (or the fp16 subnormal
+    spacing), in the [k-step][out block][split][lane][8] order the kernels read."""
+    from codlad_amd.weights import pack_block_h
+    g = torch.Generator().manual_seed(4)
+    W = torch.randn(128, 128, generator=g) * 0.13
+    W[5, 77] = 3.0
+    pk = pack_block_h(W).view(torch.float16).view(8, 4, 2, 64, 8)
+    ks, bo, lane, j = 5, 3, 41, 6
+    row = 32 * bo + (lane & 31)
+    col = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
+    rec = pk[ks, bo, 0, lane, j].double() + pk[ks, bo, 1, lane, j].double()
+    assert abs(float(rec) - float(W[row, col])) <= max(2.0 ** -22 * abs(float(W[row, col])), 2.0 ** -25)
+    # whole block: every element exactly once, error bound everywhere
+    rec_all = (pk[:, :, 0].double() + pk[:, :, 1].double()).reshape(-1)
+    assert torch.allclose(rec_all.sort().values, W.double().reshape(-1).sort().values, rtol=2.0 ** -21, atol=2.0 ** -24)
+    two = pack_block_h(W, 2.0).view(torch.float16).view(8, 4, 2, 64, 8)
+    assert torch.equal(two, pk * 2)          # power-of-two scaling is exact
 
 
 @pytest.mark.parametrize("T", ["10", "100", "250"])
