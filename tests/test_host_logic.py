@@ -79,7 +79,8 @@ def test_f16x4_block_packing():
     rec_all = (pk[:, :, 0].double() + pk[:, :, 1].double()).reshape(-1)
     assert torch.allclose(rec_all.sort().values, W.double().reshape(-1).sort().values, rtol=2.0 ** -21, atol=2.0 ** -24)
     two = pack_block_h(W, 2.0).view(torch.float16).view(8, 4, 2, 64, 8)
-    assert torch.equal(two, pk * 2)          # power-of-two scaling is exact
+    rec2 = (two[:, :, 0].double() + two[:, :, 1].double()).reshape(-1)
+    assert torch.allclose(rec2, 2 * rec_all, rtol=2.0 ** -21, atol=2.0 ** -24)   # decoder blocks carry the factor 2
 
 
 @pytest.mark.parametrize("T", ["10", "100", "250"])
