@@ -47,12 +47,13 @@ def algorithmic_flop_per_structure(L):
 class Workload:
     """cfg 2 resident on one GPU."""
 
-    def __init__(self, device, rank):
+    def __init__(self, device, rank, precision="f16x4"):
         from codlad_amd import synth
         from codlad_amd.engine import Decoder, Denoiser
         from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
         self.device = device
-        self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), device)
+        self.precision = precision
+        self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), device, precision=precision)
         mean, std = synth.norm_stats("PED", "N6")
         self.dec = Decoder(synth.vqvae_state_dict("N6", "PED", VAE_SEED), device, mean, std)
         self.tables = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T_STEPS)))
@@ -181,6 +182,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f16x4", "f32"], default="f16x4",
+                    help="contraction mode: f16x4 = fp16 hi/lo split operands on the f16 matrix pipe with fp32 "
+                         "accumulation (fp32-equivalent, default); f32 = v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -200,7 +204,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    wl = Workload(device, rank)
+    wl = Workload(device, rank, args.precision)
     if world > 1:
         # weights travel once, rank 0 -> all, as one buffer each (RCCL broadcast over xGMI)
         from codlad_amd.parallel import broadcast_weights
@@ -244,6 +248,9 @@ def main():
             "value": value, "unit": "structures/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "precision": ("f16x4: fp32 operands split into fp16 hi+lo (|eps| <= 2^-22), 4 f16 MFMAs per product, fp32 "
+                          "accumulate; all other arithmetic fp32" if args.precision == "f16x4" else
+                          "f32: v_mfma_f32_32x32x2_f32, all arithmetic fp32"),
             "config": {"workload": "cfg2: PED-shaped test set, 4 proteins L=46/87/92/129 x 10 frames x "
                                    "num_ensemble 10 = 400 structures per GPU, 100-step DDPM (mpnn_diffusion) + "
                                    "VQ(4096x3) + IC_Decoder N6 + ic_to_xyz",
@@ -251,7 +258,13 @@ def main():
                        "edges_per_gpu": wl.n_edges, "ddpm_steps": T_STEPS, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "edge_kernel<false> (encoder message MLP, layers 1-2)",
+                         "kernel": ("edge_kernel_h<false> " if args.precision == "f16x4" else "edge_kernel<false> ") +
+                                   "(encoder message MLP, layers 1-2)",
+                         "peak_note": "fp32 matrix peak of MI355X_MICROARCH.md; algorithmic FLOP of SURVEY.md 8d "
+                                      "(the kernel executes half of them after the W1 split, and in f16x4 mode "
+                                      "runs them on the f16 pipe), so frac may exceed 1",
+                         "f16_pipe_frac": (4 * 2.0 * 2 * 128 * 128 * wl.n_edges / kern["message"] / 2.5e15
+                                           if args.precision == "f16x4" else None),
                          "launch_ms": kern["message"] * 1e3,
                          "algorithmic_flop_per_launch": flop_launch,
                          "executed_flop_per_launch": 2.0 * 2 * 128 * 128 * wl.n_edges,

@@ -44,6 +44,7 @@ def build(force=False, verbose=True):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(d) for d in [src] + HEADERS):
             cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(s, []) + \
+                  os.environ.get("CODLAD_CXXFLAGS", "").split() + \
                   ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -152,7 +152,9 @@ DEV f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
 DEV void mfma_f16x4(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
     // smallest terms first
+#ifndef CODLAD_F16X3
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.lo, acc, 0, 0, 0);
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.hi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.hi, acc, 0, 0, 0);

@@ -154,28 +154,32 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
             const bool valid = half ? validB : validA;
             const int colc = half ? colB : colA, col = 32 * half + c;
             const int j = half ? jB : jA;
-            Tile x, acc;
+            Tile x, acc, t2;
             tile_load_row(x, rows + (size_t)colc * HD, h);
             tile_load_row(acc, Prow, h);
             tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
             gemm128_h_lds<false>(acc, x, w1, lane);          // layer 1
-            tile_load_row(x, a.b2, h);
-            gemm128_h_lds<true>(x, acc, w2, lane);           // layer 2 on GELU(layer 1), GELU under the MFMAs
+            tile_load_row(t2, a.b2, h);
+            gemm128_h_lds<true>(t2, acc, w2, lane);          // layer 2 on GELU(layer 1), GELU under the MFMAs
             if (!EDGE_UPDATE) {
-                tile_gelu(x);
-                tile_colsum(x, valid);
+                tile_gelu(t2);
+                tile_colsum(t2, valid);
                 if (half == 0) {
-                    sum = x;
+                    sum = t2;
                 } else {
 #pragma unroll
-                    for (int bo = 0; bo < 4; ++bo) x.b[bo] += sum.b[bo];
+                    for (int bo = 0; bo < 4; ++bo) t2.b[bo] += sum.b[bo];
                 }
-                if (c == 31 && (half == 1 || !two)) tile_store_row(x, a.S + (size_t)n * HD, h);
+                if (c == 31 && (half == 1 || !two)) tile_store_row(t2, a.S + (size_t)n * HD, h);
             } else {
-                tile_load_row(acc, a.b3, h);
-                gemm_h_lds<0, 4, true>(acc, x, w3, lane, NoSideWork());      // layer 3 on GELU(layer 2)
-                gemm_h_glb<4, 4, true>(acc, x, a.W3h, lane, NoSideWork());
-                edge_epilogue(acc, rows + (size_t)colc * HD, out_rows + (size_t)col * HD, a.mods3, valid, h);
+                // layer 3 accumulates onto h_E + b13: the input tile stays in registers for the
+                // residual instead of being fetched from HBM a second time
+                tile_add_row(x, a.b3, h);
+                gemm_h_lds<0, 4, true>(x, t2, w3, lane, NoSideWork());       // layer 3 on GELU(layer 2)
+                gemm_h_glb<4, 4, true>(x, t2, a.W3h, lane, NoSideWork());
+                tile_layernorm(x, 1e-6f);
+                tile_modulate(x, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);
+                if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);
             }
         }
     }
