@@ -236,6 +236,13 @@ def main():
         dt = float(tmax)
 
     kern = wl.time_dominant_kernel()
+    # HBM bytes per launch of the dominant kernel: PMC counters need rocprofv3, so the figure comes from
+    # the committed profile of this same workload (profiles/README.md says how it was taken)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+    if args.precision == "f16x4" and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
     if rank == 0:
         total_structs = wl.n_structures * world * args.steps
         value = total_structs / dt
@@ -257,7 +264,7 @@ def main():
                        "structures_per_gpu": wl.n_structures, "nodes_per_gpu": wl.job.n_nodes,
                        "edges_per_gpu": wl.n_edges, "ddpm_steps": T_STEPS, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": ("edge_kernel_h<false> " if args.precision == "f16x4" else "edge_kernel<false> ") +
                                    "(encoder message MLP, layers 1-2)",
                          "peak_note": "fp32 matrix peak of MI355X_MICROARCH.md; algorithmic FLOP of SURVEY.md 8d "
