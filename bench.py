@@ -138,10 +138,10 @@ class Workload:
 
 
 def cpu_baseline():
-    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample: 2 frames of
-    the L=87 protein, 10 of the 100 DDPM steps run as the reference runs them (batch duplicated,
+    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample: 4 frames of
+    the L=87 protein, 20 of the 100 DDPM steps run as the reference runs them (batch duplicated,
     test.py:505; CA features recomputed every step), plus the decoder tail; extrapolated linearly
-    to 100 steps."""
+    to 100 steps (every step costs the same)."""
     from codlad_amd import synth
     from oracle import denoiser as oden, sampler as osam, vae_decode as odec
     torch.set_grad_enabled(False)
@@ -155,7 +155,7 @@ def cpu_baseline():
     sd = synth.denoiser_state_dict(WEIGHT_SEED)
     vsd = synth.vqvae_state_dict("N6", "PED", VAE_SEED)
     mean, std = synth.norm_stats("PED", "N6")
-    L, B, Tsub = 87, 2, 10
+    L, B, Tsub = 87, 4, 20
     prot = synth.make_protein(L, 1001, n_frames=B)
     batch = synth.make_batch(prot)
     cg_z, cg_xyz, mask = oden.batch_to_dense(batch)

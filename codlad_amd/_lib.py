@@ -78,6 +78,7 @@ _SIGS = {
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, P]),
     "codlad_selftest_gemm128": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
+    "codlad_selftest_gemm128_h": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
 }
 
 _lib = None

@@ -163,16 +163,9 @@ DEV void mfma_f16x4(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
 // acc += W(128x128, f16x4-packed block in LDS) @ in.  128 f16 MFMAs in 32 groups (k-step, out
 // block) of four; weight fragments are read from LDS two groups ahead through a register ring.
 //
-// `side(ks)` is called once per k-step with independent fp32 work (GELU / reduction / LayerNorm
-// of ANOTHER tile).  Measured on MI355X (tools/ubench/coexec.hip): VALU instructions placed
-// between the f16 MFMAs of the SAME wave are hidden behind the matrix pipe (32 MFMA + 128 v_fma
-// take the time of the 32 MFMAs), while the same VALU work in the partner wave of the SIMD adds
-// ~55 % of its own time.  So each wave software-pipelines two column tiles and overlaps the
-// epilogue of one with the contraction of the other.
-struct NoSideWork {
-    DEV void operator()(int, int) const {}
-};
-
+// Measured on MI355X (tools/ubench/fill.hip, coexec.hip): fp32 VALU work placed between f16 MFMAs
+// is mostly NOT hidden (75-85 % of its stand-alone time is exposed, in the same wave or in the
+// SIMD partner), only transcendentals are; so the goal is simply the fewest VALU instructions.
 template <int N>
 DEV void gelu_pairs(f32x2 (&x)[N]);
 
@@ -198,14 +191,12 @@ DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
 }
 
 // One group = (k-step ks, out block bo): fragment prefetch for two groups ahead, a quarter of
-// the NEXT k-step's operand split, four MFMAs, and side(ks, bo) - a quarter of the side work of
-// this k-step (one register pair of another tile).  The sched_barrier closes the scheduling
-// region: inside it the compiler interleaves the ~25-35 VALU instructions with the four MFMAs
-// (128 matrix-pipe cycles); across it nothing moves, which keeps register pressure bounded
-// (left alone, hipcc hoists loads and epilogue arithmetic across the whole 128-MFMA block and
-// spills hundreds of registers).
-template <int KS0, int NKS, bool GELU_IN, typename Side>
-DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, Side side) {
+// the NEXT k-step's operand split (and GELU), four MFMAs.  The sched_barrier closes the
+// scheduling region: inside it the compiler interleaves the VALU instructions with the four
+// MFMAs; across it nothing moves, which keeps register pressure bounded (left alone, hipcc hoists
+// loads and epilogue arithmetic across the whole 128-MFMA block and spills hundreds of registers).
+template <int KS0, int NKS, bool GELU_IN>
+DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
     const u32x4 *w = wl + lane;
     constexpr int G0 = KS0 * 4, NG = NKS * 4;
     u32x4 ring[3][2];
@@ -226,7 +217,6 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, Side s
         }
         if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
         mfma_f16x4(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
-        side(ks, bo);
         __builtin_amdgcn_sched_barrier(0);
         if (bo == 3) x = xn;
     }
@@ -235,7 +225,7 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, Side s
 // acc += W @ act(in): GELU_IN applies GELU to `in` on the fly (see split_pair)
 template <bool GELU_IN>
 DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
-    gemm_h_lds<0, 8, GELU_IN>(acc, in, wl, lane, NoSideWork());
+    gemm_h_lds<0, 8, GELU_IN>(acc, in, wl, lane);
 }
 
 // The same k-step with the weight fragments fetched from global memory (L2-resident) through a
@@ -244,8 +234,8 @@ DEV u32x4 weight_frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, frag_index * 1024, 0));
 }
 
-template <int KS0, int NKS, bool GELU_IN, typename Side>
-DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, Side side) {
+template <int KS0, int NKS, bool GELU_IN>
+DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wpacked), 0, 65536, 0x00020000);
     constexpr int G0 = KS0 * 4, NG = NKS * 4;
@@ -267,14 +257,9 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, Si
         }
         if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
         mfma_f16x4(acc.b[bo], as_f16x8(ring[g & 3][0]), as_f16x8(ring[g & 3][1]), x);
-        side(ks, bo);
         __builtin_amdgcn_sched_barrier(0);
         if (bo == 3) x = xn;
     }
-}
-
-DEV void gemm128_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
-    gemm_h_glb<0, 8, false>(acc, in, Wpacked, lane, NoSideWork());
 }
 
 // GELU(x) = (0.5 x)(1 + erf(x/sqrt 2)), erf to <= 8.3e-8 absolute (fp32 erf has ulp 6e-8 near 1).
@@ -385,22 +370,6 @@ DEV void tile_gelu(Tile &t) {
                 t.b[bo][r + 2 * i + 1] = v[i].y;
             }
         }
-#endif
-}
-
-// GELU of one register pair: pair p (0..3) of k-step slice ks (8 registers) of a tile - the unit
-// of side work attached to one MFMA group.
-DEV void tile_gelu_pair(Tile &t, int ks, int p) {
-    f32x16 &blk = t.b[ks >> 1];
-    const int r = (ks & 1) * 8 + 2 * p;
-#ifdef CODLAD_EXACT_ERF
-    blk[r] = gelu_erf(blk[r]);
-    blk[r + 1] = gelu_erf(blk[r + 1]);
-#else
-    f32x2 v[1] = {f32x2{blk[r], blk[r + 1]}};
-    gelu_pairs<1>(v);
-    blk[r] = v[0].x;
-    blk[r + 1] = v[0].y;
 #endif
 }
 

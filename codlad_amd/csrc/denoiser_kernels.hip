@@ -109,14 +109,6 @@ DEV void tile_colsum(Tile &t, bool valid) {
         for (int p = 0; p < 4; ++p) tile_colsum_pair(t, ks, p, valid);
 }
 
-// edge-update epilogue of one 32-column tile: h_E <- gate3 * mod3(LN(h_E + message))
-DEV void edge_epilogue(Tile &acc, const float *row_in, float *row_out, const float *mods3, bool valid, int h) {
-    tile_add_row(acc, row_in, h);
-    tile_layernorm(acc, 1e-6f);
-    tile_modulate(acc, mods3, mods3 + HD, mods3 + 2 * HD, h);
-    if (valid) tile_store_row(acc, row_out, h);
-}
-
 template <bool EDGE_UPDATE, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
@@ -175,8 +167,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
                 // layer 3 accumulates onto h_E + b13: the input tile stays in registers for the
                 // residual instead of being fetched from HBM a second time
                 tile_add_row(x, a.b3, h);
-                gemm_h_lds<0, 4, true>(x, t2, w3, lane, NoSideWork());       // layer 3 on GELU(layer 2)
-                gemm_h_glb<4, 4, true>(x, t2, a.W3h, lane, NoSideWork());
+                gemm_h_lds<0, 4, true>(x, t2, w3, lane);       // layer 3 on GELU(layer 2)
+                gemm_h_glb<4, 4, true>(x, t2, a.W3h, lane);
                 tile_layernorm(x, 1e-6f);
                 tile_modulate(x, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);
                 if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);
@@ -791,6 +783,27 @@ __global__ __launch_bounds__(64) void selftest_kernel(const float *Wp, const flo
     gemm128(acc, in, Wp, lane);
     if (act) tile_gelu(acc);
     if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
+}
+
+__global__ __launch_bounds__(64) void selftest_h_kernel(const void *Wh, const float *bias, const float *X,
+                                                        int n_rows, int act, float *Y) {
+    const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
+    const int row = blockIdx.x * 32 + c;
+    const int rc = row < n_rows ? row : n_rows - 1;
+    Tile in, acc;
+    tile_load_row(in, X + (size_t)rc * HD, h);
+    tile_load_row(acc, bias, h);
+    if (act) gemm_h_glb<0, 8, true>(acc, in, Wh, lane);    // Y = W gelu(X) + b
+    else gemm_h_glb<0, 8, false>(acc, in, Wh, lane);       // Y = W X + b
+    if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
+}
+
+extern "C" int codlad_selftest_gemm128_h(const void *W_f16x4, const float *bias, const float *X, int n_rows,
+                                         int act_in, float *Y, void *stream) {
+    CODLAD_REQUIRE(W_f16x4 && bias && X && Y && n_rows > 0, "bad arguments");
+    hipLaunchKernelGGL(selftest_h_kernel, dim3((n_rows + 31) / 32), dim3(64), 0, (hipStream_t)stream,
+                       W_f16x4, bias, X, n_rows, act_in, Y);
+    return codlad_check_launch("codlad_selftest_gemm128_h");
 }
 
 extern "C" int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X,

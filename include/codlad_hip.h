@@ -206,6 +206,11 @@ int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *no
 int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X, int n_rows,
                             int act, float *Y, void *stream);
 
+/* Same for the f16x4 contraction: Y[n][:] = W @ act_in(X[n][:]) + bias with W packed by the f16x4
+ * order (codlad_amd.weights.pack_block_h); act_in: 0 = none, 1 = GELU applied to the input. */
+int codlad_selftest_gemm128_h(const void *W_f16x4, const float *bias, const float *X, int n_rows,
+                              int act_in, float *Y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,33 @@ def test_mfma_chain_primitive(act):
     assert rel_err(Y, ref) < 2e-6
 
 
+def test_f16x4_chain_primitive_is_exact_on_integers():
+    """Operand lane maps of v_mfma_f32_32x32x16_f16 + the hi/lo packing, checked with small integers
+    (exact in fp16, so any mapping error shows as a wrong integer, not as rounding)."""
+    from codlad_amd.weights import pack_block_h
+    g = torch.Generator().manual_seed(6)
+    W = torch.randint(-8, 9, (128, 128), generator=g).float()
+    W[3, 7] = 100.0  # asymmetric marker
+    b = torch.randint(-50, 50, (128,), generator=g).float()
+    X = torch.randint(-16, 17, (77, 128), generator=g).float()
+    Y = torch.empty(77, 128, device=DEV)
+    Wh, bd, Xd = pack_block_h(W).to(DEV), b.to(DEV), X.to(DEV)
+    rc = _lib.lib().codlad_selftest_gemm128_h(_lib.ptr(Wh), _lib.ptr(bd), _lib.ptr(Xd), 77, 0, _lib.ptr(Y), None)
+    _lib.check(rc, "selftest_h")
+    torch.cuda.synchronize()
+    assert torch.equal(Y.cpu(), X @ W.t() + b)
+    # non-representable operands: hi/lo split keeps fp32-level accuracy; GELU fused into the input side
+    W2 = torch.randn(128, 128, generator=g) / 11.0
+    X2 = torch.randn(77, 128, generator=g) * 3.0
+    W2h, X2d = pack_block_h(W2).to(DEV), X2.to(DEV)
+    for act in (0, 1):
+        rc = _lib.lib().codlad_selftest_gemm128_h(_lib.ptr(W2h), _lib.ptr(bd), _lib.ptr(X2d), 77, act, _lib.ptr(Y), None)
+        _lib.check(rc, "selftest_h")
+        torch.cuda.synchronize()
+        xin = torch.nn.functional.gelu(X2.double()) if act else X2.double()
+        assert rel_err(Y, xin @ W2.double().t() + b.double()) < 2e-6
+
+
 @pytest.mark.parametrize("name", list(cases.DENOISER_CASES))
 def test_features_prepass(den, sd, name):
     L, B, seed = cases.DENOISER_CASES[name]
@@ -132,6 +159,23 @@ def test_denoiser_forward(den, sd, name):
     assert rel_err(out, gold["out"]) < 1e-5
     if "enc0_hV" in gold.files:  # intermediate left in the workspace: last decoder h_V
         assert rel_err(job.hV.cpu().view(B, L, 128), gold["dec2_hV"]) < 1e-5
+
+
+@pytest.mark.parametrize("L", [5, 31, 32, 33, 63, 64, 65, 200, 505])
+def test_denoiser_forward_edge_lengths(den, sd, L):
+    """Tile boundaries of the kernels: K = L < 32 (one partly filled column tile), 32/33 (second tile
+    empty / one column), 63/64/65 (K saturates at 64), and the longest Atlas test protein (505)."""
+    prot = synth.make_protein(L, 70 + L, n_frames=1)
+    batch = synth.make_batch(prot)
+    x = synth.gaussian((1, L, 3), 5)
+    t = torch.tensor([777])
+    st = structures_of(den, prot)
+    job = den.make_job(st, [0])
+    out = den.forward(job, x.reshape(-1, 3).to(DEV), 777).cpu().view(1, L, 6)
+    cg_z, cg_xyz, m = oden.batch_to_dense(batch)
+    ref = oden.forward(sd, x, t, cg_xyz, cg_z, m)
+    assert bool(torch.isfinite(out).all())
+    assert rel_err(out, ref) < 1e-5
 
 
 def test_ensemble_members_share_structure(den, sd):
