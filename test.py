@@ -82,9 +82,18 @@ def iter_batches(args):
 def main(args):
     if not torch.cuda.is_available():
         raise SystemExit("test.py (codlad_amd) needs an MI355X: there is no CPU path")
-    device = "cuda"
+    # one process per GPU under torch.distributed.run: batches (independent units) are dealt to the
+    # ranks longest-first, every rank samples and decodes its own, rank 0 reports the totals
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
     torch.set_grad_enabled(False)
-    torch.manual_seed(args.seed + args.sample_index)
+    torch.manual_seed(args.seed + args.sample_index + 1000 * rank)
     np.random.seed(args.seed + args.sample_index)
     if args.cfg_scale > 1.0:
         raise NotImplementedError("cfg_scale > 1 calls model.forward_with_cfg, which the reference model "
@@ -100,7 +109,12 @@ def main(args):
     save_dir = f"./logs/generated_samples_{args.sample_index}_{args.model_step}/{args.exp}_{args.data_type}"
     os.makedirs(save_dir, exist_ok=True)
     total, t_all = 0, time.time()
-    for name, batch, info in iter_batches(args):
+    units = list(iter_batches(args))
+    if world > 1:
+        from codlad_amd.parallel import shard_units, unit_cost
+        costs = [int(b["num_CGs"].shape[0]) * unit_cost(int(b["num_CGs"][0])) for _n, b, _i in units]
+        units = [units[u] for u in shard_units(costs, world)[rank]]
+    for name, batch, info in units:
         batch = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in batch.items()}
         B = int(batch["num_CGs"].shape[0])
         L = int(batch["num_CGs"][0])
@@ -132,7 +146,14 @@ def main(args):
         np.save(os.path.join(save_dir, f"{name}_xyz_recon.npy"), xyz.cpu().numpy())
         print(f"{name}: {B} frames x {E} members, L={L}, {xyz.shape[2]} atoms: {dt:.2f}s "
               f"({B * E / dt:.1f} structures/s)", flush=True)
-    print(f"done: {total} structures in {time.time() - t_all:.1f}s -> {save_dir}")
+    if world > 1:
+        import torch.distributed as dist
+        tot = torch.tensor([total], dtype=torch.int64, device=device)
+        dist.all_reduce(tot)
+        total = int(tot)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(f"done: {total} structures on {world} GPU(s) in {time.time() - t_all:.1f}s -> {save_dir}")
 
 
 if __name__ == "__main__":
