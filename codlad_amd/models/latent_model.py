@@ -120,6 +120,9 @@ class ProteinMPNN_diffusion_new(nn.Module):
         for layer in list(self.encoder_layers) + list(self.decoder_layers) + [self.W_out]:
             nn.init.constant_(layer.adaLN_modulation[-1].weight, 0)
             nn.init.constant_(layer.adaLN_modulation[-1].bias, 0)
+        # contraction mode of the HIP kernels: "f16x4" (default, fp32-equivalent split-fp16 products on
+        # the f16 matrix pipe) or "f32" (v_mfma_f32_32x32x2_f32); see DESIGN.md §4
+        self.precision = "f16x4"
         self._engine = None
         self._engine_key = None
         self._job_cache = {}
@@ -127,10 +130,10 @@ class ProteinMPNN_diffusion_new(nn.Module):
     # -- HIP engine plumbing ---------------------------------------------------------------------
     def engine(self):
         """Packed device weights; rebuilt whenever a parameter changed or moved."""
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters()) + (self.precision,)
         if self._engine is None or key != self._engine_key:
             dev = next(self.parameters()).device
-            self._engine = Denoiser(self.state_dict(), dev)
+            self._engine = Denoiser(self.state_dict(), dev, precision=self.precision)
             self._engine_key = key
             self._job_cache.clear()
         return self._engine
