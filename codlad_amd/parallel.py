@@ -28,10 +28,19 @@ def unit_cost(L):
     return L * min(64, L)
 
 
+def _stage(t):
+    """gloo (CPU tests / single-GPU rehearsal) moves CUDA tensors through host memory; RCCL takes
+    them as they are."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
 def broadcast_weights(*weight_sets, src=0):
     """Overwrite every rank's blobs with rank `src`'s (layout is shape-derived, hence identical)."""
     for ws in weight_sets:
-        dist.broadcast(ws.blob.data, src=src)
+        buf = _stage(ws.blob.data)
+        dist.broadcast(buf, src=src)
+        if buf is not ws.blob.data:
+            ws.blob.data.copy_(buf)
         ws.rebind()
 
 
@@ -40,6 +49,7 @@ def gather_coordinates(xyz_list, world_size):
     tensor list is flattened to one buffer, padded to the largest rank's size and trimmed after.
     Returns a list (per rank) of flat fp32 tensors."""
     flat = torch.cat([x.reshape(-1) for x in xyz_list]) if len(xyz_list) else torch.zeros(0)
+    flat = _stage(flat)
     n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
     sizes = [torch.zeros_like(n) for _ in range(world_size)]
     dist.all_gather(sizes, n)
