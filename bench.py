@@ -77,11 +77,7 @@ class Workload:
         ni = self.job.node_info
         self.cg_z = ni[:, 3].contiguous()
         self.cg_xyz = self.structures.xyz[ni[:, 0].long()].contiguous()
-        pairs = []
-        for s, f in enumerate(sample_struct):
-            xyz = xyz_list[f]
-            pairs.append(synth.cg_nbr_list(xyz) + int(self.job.sample_off[s]))
-        self.csr = Decoder.csr_from_pairs(torch.cat(pairs).to(device), self.job.n_nodes)
+        self.csr = self.dec.build_csr(self.cg_xyz, self.job.sample_lens)   # CG graph within 21 A, on the device
         self.n_edges = int(ni[:, 2].sum())
         self.ca_full = []
         for start, count, prot in self.groups:

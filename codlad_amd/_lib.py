@@ -74,6 +74,7 @@ _SIGS = {
                                      C.POINTER(Workspace), P]),
     "codlad_vq_lookup": (C.c_int, [P, C.c_int, P, P, P, C.c_int, P, P, P, P]),
     "codlad_ic_decode": (C.c_int, [C.POINTER(DecoderWeights), P, P, P, P, P, C.c_int, P, P, P]),
+    "codlad_cg_graph": (C.c_int, [P, P, C.c_int, C.c_float, P, P, P, P]),
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, P]),

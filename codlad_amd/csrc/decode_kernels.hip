@@ -204,6 +204,54 @@ extern "C" int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_
 }
 
 // ---------------------------------------------------------------------------------------------
+// SURVEY 8f-3 (host preprocessing moved to the device): the CG neighbour list of the IC decoder.
+// Reference: get_neighbor_list(xyz, cutoff=cg_cutoff) keeps the pairs j > i with
+// sqrt(sum((x_i - x_j)^2)) <= cutoff (utils/protein_module.py:567-584); make_directed appends the
+// flipped pairs (models/gcn_nn.py:54-64) and scatter_add sums per receiving node in list order
+// (models/vae_model.py:485-488).  Built directly as CSR over the receiver: for node i first the
+// senders j > i in ascending order, then the senders j < i in ascending order.
+// One wave per node; pass 1 counts, pass 2 (after an exclusive scan of the counts) fills.
+// ---------------------------------------------------------------------------------------------
+DEV bool cg_within(const float *xyz, int i, int j, float cutoff) {
+    const float dx = xyz[3 * i] - xyz[3 * j], dy = xyz[3 * i + 1] - xyz[3 * j + 1], dz = xyz[3 * i + 2] - xyz[3 * j + 2];
+    return sqrtf((dx * dx + dy * dy) + dz * dz) <= cutoff;     // -ffp-contract=off: rounded like the reference
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void cg_graph_kernel(const float *xyz, const int2 *range, int M, float cutoff,
+                                                      int32_t *degree, const int32_t *csr_ptr, int32_t *csr_src) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    const int first = range[i].x, last = first + range[i].y;   // nodes of i's sample: [first, last)
+    int count = FILL ? csr_ptr[i] : 0;
+    // senders j > i, then j < i, each ascending; 64 candidates per step, order kept by ballot ranks
+    for (int phase = 0; phase < 2; ++phase) {
+        const int lo = phase == 0 ? i + 1 : first, hi = phase == 0 ? last : i;
+        for (int j0 = lo; j0 < hi; j0 += 64) {
+            const int j = j0 + lane;
+            const bool in = j < hi && cg_within(xyz, i, j, cutoff);
+            const unsigned long long m = __ballot(in);
+            if (FILL && in) csr_src[count + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            count += __popcll(m);
+        }
+    }
+    if (!FILL && lane == 0) degree[i] = count;
+}
+
+extern "C" int codlad_cg_graph(const float *cg_xyz, const int32_t *sample_range, int M, float cutoff,
+                               int32_t *degree, const int32_t *csr_ptr, int32_t *csr_src, void *stream) {
+    CODLAD_REQUIRE(cg_xyz && sample_range && M > 0, "bad arguments");
+    CODLAD_REQUIRE((degree != nullptr) != (csr_ptr != nullptr && csr_src != nullptr),
+                   "pass either degree (count pass) or csr_ptr + csr_src (fill pass)");
+    dim3 grid((M + 3) / 4), block(256);
+    const int2 *rg = reinterpret_cast<const int2 *>(sample_range);
+    if (degree) hipLaunchKernelGGL(cg_graph_kernel<false>, grid, block, 0, (hipStream_t)stream, cg_xyz, rg, M, cutoff, degree, nullptr, nullptr);
+    else hipLaunchKernelGGL(cg_graph_kernel<true>, grid, block, 0, (hipStream_t)stream, cg_xyz, rg, M, cutoff, nullptr, csr_ptr, csr_src);
+    return codlad_check_launch("codlad_cg_graph");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row 10.  One thread per (frame, residue): 13 sequential z-matrix placements.
 // ---------------------------------------------------------------------------------------------
 struct V3 { float x, y, z; };

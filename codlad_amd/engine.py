@@ -216,6 +216,31 @@ class Decoder:
         ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         return ptr, src
 
+    def build_csr(self, cg_xyz, sample_lens, cutoff=21.0):
+        """Directed CG graph of every sample as CSR, on the device (what the reference's host
+        preprocessing + make_directed + scatter order amount to).  cg_xyz [M,3] flat over samples,
+        sample_lens: residues per sample."""
+        xyz = cg_xyz.to(self.device).contiguous().float()
+        M = xyz.shape[0]
+        assert sum(sample_lens) == M
+        rng = np.empty((M, 2), dtype=np.int32)
+        o = 0
+        for L in sample_lens:
+            rng[o:o + L, 0] = o
+            rng[o:o + L, 1] = L
+            o += L
+        rng = torch.from_numpy(rng).to(self.device)
+        deg = torch.empty(M, dtype=torch.int32, device=self.device)
+        st = _lib.stream_ptr(self.device)
+        _lib.check(self.lib.codlad_cg_graph(_lib.ptr(xyz), _lib.ptr(rng), M, C.c_float(cutoff), _lib.ptr(deg),
+                                            None, None, st), "codlad_cg_graph(count)")
+        ptr = torch.zeros(M + 1, dtype=torch.int32, device=self.device)
+        ptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+        src = torch.empty(max(int(ptr[-1]), 1), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.codlad_cg_graph(_lib.ptr(xyz), _lib.ptr(rng), M, C.c_float(cutoff), None,
+                                            _lib.ptr(ptr), _lib.ptr(src), st), "codlad_cg_graph(fill)")
+        return ptr, src[:int(ptr[-1])]
+
     def ic_decode(self, z_q, cg_z, cg_xyz, pairs=None, csr=None):
         """z_q [M,3], cg_z [M], cg_xyz [M,3] and either the undirected CG pairs [E,2] (flat node
         indices, as in batch['CG_nbr_list']) or a prebuilt csr = (ptr, src) -> ic [M,13,3]."""

@@ -185,6 +185,15 @@ int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_q, const in
                      const float *cg_xyz, const int32_t *csr_ptr, const int32_t *csr_src,
                      int M, float *scratch, float *ic_out, void *stream);
 
+/* Next row 8f-3 (host preprocessing): CG neighbour list within `cutoff` (reference
+ * utils/protein_module.py:567-584) + make_directed + scatter order (models/gcn_nn.py:54-64,
+ * models/vae_model.py:485-488), as the CSR codlad_ic_decode consumes.  sample_range[i] = {first, L}
+ * of the sample that flat node i belongs to.  Two passes: degree != NULL counts the directed edges
+ * arriving at every node; after an exclusive scan into csr_ptr, the second call (degree == NULL)
+ * writes csr_src (for node i: senders j > i ascending, then j < i ascending). */
+int codlad_cg_graph(const float *cg_xyz, const int32_t *sample_range, int M, float cutoff,
+                    int32_t *degree, const int32_t *csr_ptr, int32_t *csr_src, void *stream);
+
 /* Row 10: ic_to_xyz (utils/utils_ic.py:242-268).  ca_full [B][L+2][3] (flanking residues
  * included), ic [B][L][13][3], orders int32 [10][L][3] (atom_orders), slot_to_out int32 [L*14]
  * (output atom index of each residue slot, -1 = slot unused; derived from info's

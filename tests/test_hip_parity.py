@@ -340,6 +340,25 @@ def test_ic_decode_and_xyz(name):
         assert my_err < 4 * ref_err + 2e-5, (my_err, ref_err)
 
 
+def test_cg_graph_on_device_equals_reference_neighbour_list():
+    """codlad_cg_graph == get_neighbor_list + make_directed + receiver-sorted scatter order."""
+    dec = Decoder(synth.vqvae_state_dict("N6", "PED", cases.VAE_SEED), DEV)
+    lens, xyzs, pairs, off = [], [], [], 0
+    for L, seed in ((5, 1), (46, 2), (129, 3), (300, 4)):
+        xyz = torch.from_numpy(synth.make_protein(L, seed)["xyz_full"][0, 1:-1])
+        lens.append(L); xyzs.append(xyz)
+        pairs.append(synth.cg_nbr_list(xyz) + off)
+        off += L
+    ptr, src = dec.build_csr(torch.cat(xyzs), lens)
+    rptr, rsrc = Decoder.csr_from_pairs(torch.cat(pairs), off)
+    assert torch.equal(ptr.cpu(), rptr) and torch.equal(src.cpu(), rsrc)
+    # a tighter cutoff exercises the distance test itself
+    p8 = synth.cg_nbr_list(xyzs[2], cutoff=8.0)
+    ptr8, src8 = dec.build_csr(xyzs[2], [129], cutoff=8.0)
+    r8 = Decoder.csr_from_pairs(p8, 129)
+    assert torch.equal(ptr8.cpu(), r8[0]) and torch.equal(src8.cpu(), r8[1])
+
+
 @pytest.mark.parametrize("name", list(cases.E2E_CASES))
 def test_end_to_end(den, sd, name):
     """noise -> xyz on the GPU vs the reference CPU path: RMSD <= 1e-4 A wherever the VQ codes agree;
