@@ -104,8 +104,9 @@ class Workload:
         return out, idx
 
     def time_dominant_kernel(self, n_launch=20):
-        """Average duration of one edge_kernel<false> launch (encoder layer 0 message MLP over
-        every edge of the job), HIP events on the stream the kernel runs on."""
+        """Average duration of one message-kernel launch (encoder layer 1: both GEMM layers over
+        every edge of the job, edge state read from HBM - what 5 of the 6 message launches of a step
+        look like), HIP events on the stream the kernel runs on."""
         from codlad_amd import _lib
         lib = _lib.lib()
         stream = torch.cuda.current_stream(self.device)
@@ -115,7 +116,7 @@ class Workload:
         def launch(which):
             rc = lib.codlad_bench_edge_launch(C.byref(self.den.weights.struct), _lib.ptr(self.job.node_info),
                                               self.job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
-                                              _lib.ptr(mods), C.byref(self.job.ws), which,
+                                              _lib.ptr(mods), C.byref(self.job.ws), which, 1,
                                               C.c_void_p(stream.cuda_stream))
             _lib.check(rc, "codlad_bench_edge_launch")
 

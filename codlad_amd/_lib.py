@@ -67,17 +67,18 @@ _SIGS = {
     "codlad_pack_block_host": (None, [P, C.c_int, C.c_float, P]),
     "codlad_features_prepass": (C.c_int, [C.POINTER(DenoiserWeights), P, P, C.c_int, C.c_int, P, P, P]),
     "codlad_step_mods": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P]),
-    "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, P, P,
+    "codlad_layer0_edge_terms": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P]),
+    "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P,
                                           C.POINTER(Workspace), P]),
     "codlad_ddpm_update": (C.c_int, [P, P, P, P, C.c_int, P, P]),
-    "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, P, P, P, C.c_int,
-                                     C.POINTER(Workspace), P]),
+    "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P,
+                                     C.c_int, C.POINTER(Workspace), P]),
     "codlad_vq_lookup": (C.c_int, [P, C.c_int, P, P, P, C.c_int, P, P, P, P]),
     "codlad_ic_decode": (C.c_int, [C.POINTER(DecoderWeights), P, P, P, P, P, C.c_int, P, P, P]),
     "codlad_cg_graph": (C.c_int, [P, P, C.c_int, C.c_float, P, P, P, P]),
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
-                                           C.POINTER(Workspace), C.c_int, P]),
+                                           C.POINTER(Workspace), C.c_int, C.c_int, P]),
     "codlad_selftest_gemm128": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
     "codlad_selftest_gemm128_h": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
 }

@@ -21,6 +21,7 @@ struct EdgeArgs {
     const int32_t *E_idx;  // [n_snodes][64]
     const float *hE_in;    // [rows][64][128]
     int in_by_src;         // 1: rows indexed by structure node (h_E0), 0: by sample node
+    const float *E1;       // encoder layer 0 only (may be null): W1e @ h_E0 per structure edge, hoisted
     float *hE_out;         // edge update only
     const float *P, *Q;    // [n_nodes][128]: own-node term (+bias), neighbour term
     const float *W1, *W2, *W3;
@@ -50,10 +51,14 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
         const int j = a.E_idx[(size_t)src * 64 + colc];
 
         Tile x, acc;
-        tile_load_row(x, rows + (size_t)colc * HD, h);
         tile_load_row(acc, Prow, h);
         tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
-        gemm128(acc, x, a.W1, lane);
+        if (a.E1) {   // layer-1 edge term precomputed per structure (step- and member-invariant)
+            tile_add_row(acc, a.E1 + ((size_t)src * 64 + colc) * HD, h);
+        } else {
+            tile_load_row(x, rows + (size_t)colc * HD, h);
+            gemm128(acc, x, a.W1, lane);
+        }
         tile_gelu(acc);
         tile_load_row(x, a.b2, h);
         gemm128(x, acc, a.W2, lane);
@@ -109,7 +114,8 @@ DEV void tile_colsum(Tile &t, bool valid) {
         for (int p = 0; p < 4; ++p) tile_colsum_pair(t, ks, p, valid);
 }
 
-template <bool EDGE_UPDATE, int NWAVES>
+// HOISTED: encoder layer 0 with a.E1 given - layer 1's edge contraction comes precomputed.
+template <bool EDGE_UPDATE, int NWAVES, bool HOISTED = false>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
     constexpr int NT = NWAVES * 64;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
         const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
         const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
         for (int i = tid; i < LDS_BLOCK_U4; i += NT) {
-            wl[i] = g1[i];
+            if (!HOISTED) wl[i] = g1[i];
             wl[LDS_BLOCK_U4 + i] = g2[i];
         }
         if (EDGE_UPDATE) {
@@ -147,10 +153,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
             const int colc = half ? colB : colA, col = 32 * half + c;
             const int j = half ? jB : jA;
             Tile x, acc, t2;
-            tile_load_row(x, rows + (size_t)colc * HD, h);
             tile_load_row(acc, Prow, h);
             tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
-            gemm128_h_lds<false>(acc, x, w1, lane);          // layer 1
+            if (HOISTED) {   // layer-1 edge term precomputed per structure (step- and member-invariant)
+                tile_add_row(acc, a.E1 + ((size_t)src * 64 + colc) * HD, h);
+                if (EDGE_UPDATE) tile_load_row(x, rows + (size_t)colc * HD, h);   // residual
+            } else {
+                tile_load_row(x, rows + (size_t)colc * HD, h);
+                gemm128_h_lds<false>(acc, x, w1, lane);      // layer 1
+            }
             tile_load_row(t2, a.b2, h);
             gemm128_h_lds<true>(t2, acc, w2, lane);          // layer 2 on GELU(layer 1), GELU under the MFMAs
             if (!EDGE_UPDATE) {
@@ -545,17 +556,24 @@ static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStrea
         const size_t lds_msg = 2 * 65536, lds_upd = 2 * 65536 + 32768;
         constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msg);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(edge_kernel_h<true, UPD_WAVES>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd);
+            const void *msg[2] = {reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES, false>),
+                                  reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES, true>)};
+            const void *upd[2] = {reinterpret_cast<const void *>(edge_kernel_h<true, UPD_WAVES, false>),
+                                  reinterpret_cast<const void *>(edge_kernel_h<true, UPD_WAVES, true>)};
+            for (int i = 0; i < 2; ++i) {
+                (void)hipFuncSetAttribute(msg[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msg);
+                (void)hipFuncSetAttribute(upd[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd);
+            }
             attr_set = true;
         }
         const int nw = update ? UPD_WAVES : MSG_WAVES;
         const int groups = (ea.n_nodes + nw - 1) / nw;
         dim3 grid(groups < num_cu() ? groups : num_cu()), block(nw * 64);
-        if (update) hipLaunchKernelGGL((edge_kernel_h<true, UPD_WAVES>), grid, block, lds_upd, st, ea);
-        else hipLaunchKernelGGL((edge_kernel_h<false, MSG_WAVES>), grid, block, lds_msg, st, ea);
+        const bool hoisted = ea.E1 != nullptr;
+        if (update && hoisted) hipLaunchKernelGGL((edge_kernel_h<true, UPD_WAVES, true>), grid, block, lds_upd, st, ea);
+        else if (update) hipLaunchKernelGGL((edge_kernel_h<true, UPD_WAVES, false>), grid, block, lds_upd, st, ea);
+        else if (hoisted) hipLaunchKernelGGL((edge_kernel_h<false, MSG_WAVES, true>), grid, block, lds_msg, st, ea);
+        else hipLaunchKernelGGL((edge_kernel_h<false, MSG_WAVES, false>), grid, block, lds_msg, st, ea);
         return;
     }
     dim3 grid((ea.n_nodes + 3) / 4), block(256);
@@ -587,8 +605,9 @@ static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t
 
 // One denoiser forward up to (not including) the final layer: leaves h_V in ws->hV.
 static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
-                            int n_nodes, const int32_t *E_idx, const float *h_E0, const float *x,
-                            const float *mods_t, const codlad_workspace *ws, hipStream_t st) {
+                            int n_nodes, const int32_t *E_idx, const float *h_E0, const float *E1,
+                            size_t n_snodes, const float *x, const float *mods_t,
+                            const codlad_workspace *ws, hipStream_t st) {
     const int4 *ni = reinterpret_cast<const int4 *>(node_info);
     const size_t NS = (size_t)n_nodes * HD;
     float *PQ0 = ws->PQ, *PQ1 = ws->PQ + NS, *PQ2 = ws->PQ + 2 * NS, *PQ3 = ws->PQ + 3 * NS;
@@ -612,6 +631,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         ea.hE_in = l == 0 ? h_E0 : ws->hE; ea.in_by_src = l == 0;
         ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
         ea.W1h = w->enc_h[l].W1e; ea.W2h = w->enc_h[l].W2;
+        if (l == 0 && E1) ea.E1 = E1;
         launch_edge(false, ea, w->precision, st);
 
         NodeArgs na = {};
@@ -649,6 +669,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         eu.P = PQ2; eu.Q = PQ3; eu.W1 = L.W11e; eu.W2 = L.W12; eu.W3 = L.W13;
         eu.b2 = L.b12; eu.b3 = L.b13; eu.mods3 = m + 6 * HD;
         eu.W1h = w->enc_h[l].W11e; eu.W2h = w->enc_h[l].W12; eu.W3h = w->enc_h[l].W13;
+        if (l == 0 && E1) eu.E1 = E1 + n_snodes * 64 * HD;
         launch_edge(true, eu, w->precision, st);
     }
     for (int l = 0; l < 3; ++l) {
@@ -696,13 +717,14 @@ extern "C" int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t 
 
 extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                                        int n_nodes, const int32_t *E_idx, const float *h_E0,
-                                       const float *x, const float *mods_t, float *out,
-                                       const codlad_workspace *ws, void *stream) {
+                                       const float *E1, int n_snodes, const float *x,
+                                       const float *mods_t, float *out, const codlad_workspace *ws,
+                                       void *stream) {
     CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && x && mods_t && out, "null pointer");
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
     CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
     hipStream_t st = (hipStream_t)stream;
-    enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, x, mods_t, ws, st);
+    enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, mods_t, ws, st);
     FinalArgs fa = {};
     fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
     fa.n_nodes = n_nodes; fa.logits = out;
@@ -722,8 +744,9 @@ extern "C" int codlad_ddpm_update(const float *x, const float *model_out, const 
 }
 
 extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_t *node_info,
-                                  int n_nodes, const int32_t *E_idx, const float *h_E0, float *x,
-                                  const float *noise, const float *mods, const float *coef, int T,
+                                  int n_nodes, const int32_t *E_idx, const float *h_E0,
+                                  const float *E1, int n_snodes, float *x, const float *noise,
+                                  const float *mods, const float *coef, int T,
                                   const codlad_workspace *ws, void *stream) {
     CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && x && noise && mods && coef, "null pointer");
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
@@ -732,7 +755,7 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
     for (int k = 0; k < T; ++k) {
         const int i = T - 1 - k;
         const float *mods_t = mods + (size_t)i * CODLAD_MODS_PER_STEP;
-        enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, x, mods_t, ws, st);
+        enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, mods_t, ws, st);
         FinalArgs fa = {};
         fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
         fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
@@ -742,28 +765,78 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
     return codlad_check_launch("codlad_sample_loop");
 }
 
+// Hoisted layer-0 edge terms: W1e(enc 0) @ h_E0 and W11e(enc 0) @ h_E0 per structure edge.  h_E0
+// depends on the CA trace only, so these two contractions are the same in every step and for every
+// ensemble member of a frame; the layer-0 kernels then start from acc = P_i + Q_j + E1[edge].
+struct Layer0Args {
+    const int2 *snode_info;
+    const float *hE0;
+    const float *W_msg, *W_upd;      // fp32-packed
+    const void *Wh_msg, *Wh_upd;     // f16x4-packed
+    float *E1;                       // [2][n_snodes][64][128]
+    int n_snodes;
+};
+
+template <bool F16X4>
+__global__ __launch_bounds__(256, 1) void layer0_kernel(Layer0Args a) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.n_snodes) return;
+    const int L = a.snode_info[m].y, K = L < 64 ? L : 64;
+    for (int half = 0; half < 2; ++half) {
+        if (32 * half >= K) break;
+        const int col = 32 * half + c;
+        const bool valid = col < K;
+        const int colc = valid ? col : 0;
+        Tile x;
+        tile_load_row(x, a.hE0 + ((size_t)m * 64 + colc) * HD, h);
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            Tile acc;
+            tile_zero(acc);
+            if (F16X4) gemm_h_glb<0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane);
+            else gemm128(acc, x, which ? a.W_upd : a.W_msg, lane);
+            if (valid) tile_store_row(acc, a.E1 + (((size_t)which * a.n_snodes + m) * 64 + col) * HD, h);
+        }
+    }
+}
+
+extern "C" int codlad_layer0_edge_terms(const codlad_denoiser_weights *w, const int32_t *snode_info,
+                                        int n_snodes, const float *h_E0, float *E1, void *stream) {
+    CODLAD_REQUIRE(w && snode_info && h_E0 && E1 && n_snodes > 0, "bad arguments");
+    Layer0Args a = {};
+    a.snode_info = reinterpret_cast<const int2 *>(snode_info); a.hE0 = h_E0; a.E1 = E1; a.n_snodes = n_snodes;
+    a.W_msg = w->enc[0].W1e; a.W_upd = w->enc[0].W11e;
+    a.Wh_msg = w->enc_h[0].W1e; a.Wh_upd = w->enc_h[0].W11e;
+    dim3 grid((n_snodes + 3) / 4), block(256);
+    if (w->precision == 1) hipLaunchKernelGGL(layer0_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(layer0_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    return codlad_check_launch("codlad_layer0_edge_terms");
+}
+
 // Single launch of one of the two edge kernels on encoder layer 0 (reads h_E0 and the P/Q left by
 // a previous forward; idempotent) - lets bench.py time the dominant kernel with HIP events.
 extern "C" int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *node_info,
                                         int n_nodes, const int32_t *E_idx, const float *h_E0,
                                         const float *mods_t, const codlad_workspace *ws, int which,
-                                        void *stream) {
+                                        int layer, void *stream) {
     CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && mods_t, "null pointer");
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
-    CODLAD_REQUIRE(n_nodes > 0 && (which == 0 || which == 1), "bad arguments");
+    CODLAD_REQUIRE(n_nodes > 0 && (which == 0 || which == 1) && (layer == 0 || layer == 1), "bad arguments");
     const size_t NS = (size_t)n_nodes * HD;
-    const codlad_enc_layer &L = w->enc[0];
+    const codlad_enc_layer &L = w->enc[layer];
     EdgeArgs ea = {};
     ea.node_info = reinterpret_cast<const int4 *>(node_info); ea.E_idx = E_idx; ea.n_nodes = n_nodes;
-    ea.hE_in = h_E0; ea.in_by_src = 1;
+    // layer 0 reads the shared structure-edge state, layer 1 the per-sample edge state (in place)
+    ea.hE_in = layer == 0 ? h_E0 : ws->hE; ea.in_by_src = layer == 0;
     if (which == 0) {
         ea.P = ws->PQ; ea.Q = ws->PQ + NS; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
-        ea.W1h = w->enc_h[0].W1e; ea.W2h = w->enc_h[0].W2;
+        ea.W1h = w->enc_h[layer].W1e; ea.W2h = w->enc_h[layer].W2;
     } else {
         ea.hE_out = ws->hE; ea.P = ws->PQ + 2 * NS; ea.Q = ws->PQ + 3 * NS;
         ea.W1 = L.W11e; ea.W2 = L.W12; ea.W3 = L.W13; ea.b2 = L.b12; ea.b3 = L.b13;
         ea.mods3 = mods_t + 6 * HD;
-        ea.W1h = w->enc_h[0].W11e; ea.W2h = w->enc_h[0].W12; ea.W3h = w->enc_h[0].W13;
+        ea.W1h = w->enc_h[layer].W11e; ea.W2h = w->enc_h[layer].W12; ea.W3h = w->enc_h[layer].W13;
     }
     launch_edge(which == 1, ea, w->precision, (hipStream_t)stream);
     return codlad_check_launch("codlad_bench_edge_launch");

@@ -42,6 +42,7 @@ class Structures:
         self.snode_info = torch.from_numpy(info).to(device)
         self.E_idx = None
         self.h_E0 = None
+        self.E1 = None        # [2][n_snodes][64][128]: hoisted layer-0 edge terms (optional)
 
 
 class Job:
@@ -93,7 +94,9 @@ class Denoiser:
         self._mods_cache = {}
 
     # -- step-invariant part -------------------------------------------------------------------
-    def prepare_structures(self, xyz_list, z_list):
+    def prepare_structures(self, xyz_list, z_list, hoist_layer0=True):
+        """k-NN graph + h_E0 per structure, and (hoist_layer0) the two layer-0 contractions of h_E0,
+        which are the same in every step and for every ensemble member (costs 2x the h_E0 memory)."""
         st = Structures(xyz_list, z_list, self.device)
         st.E_idx = torch.empty(st.n_snodes, KNN, dtype=torch.int32, device=self.device)
         st.h_E0 = torch.empty(st.n_snodes, KNN, H, dtype=torch.float32, device=self.device)
@@ -102,6 +105,12 @@ class Denoiser:
                                               _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
                                               _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_features_prepass")
+        if hoist_layer0:
+            st.E1 = torch.empty(2, st.n_snodes, KNN, H, dtype=torch.float32, device=self.device)
+            rc = self.lib.codlad_layer0_edge_terms(C.byref(self.weights.struct), _lib.ptr(st.snode_info),
+                                                   st.n_snodes, _lib.ptr(st.h_E0), _lib.ptr(st.E1),
+                                                   _lib.stream_ptr(self.device))
+            _lib.check(rc, "codlad_layer0_edge_terms")
         return st
 
     def make_job(self, structures, sample_struct):
@@ -132,8 +141,8 @@ class Denoiser:
         st = job.structures
         rc = self.lib.codlad_denoiser_forward(C.byref(self.weights.struct), _lib.ptr(job.node_info),
                                               job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
-                                              _lib.ptr(x), _lib.ptr(mods), _lib.ptr(out),
-                                              C.byref(job.ws), _lib.stream_ptr(self.device))
+                                              _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(mods),
+                                              _lib.ptr(out), C.byref(job.ws), _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_denoiser_forward")
         return out
 
@@ -151,8 +160,9 @@ class Denoiser:
         st = job.structures
         rc = self.lib.codlad_sample_loop(C.byref(self.weights.struct), _lib.ptr(job.node_info),
                                          job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
-                                         _lib.ptr(x), _lib.ptr(noise), _lib.ptr(mods), _lib.ptr(coef),
-                                         T, C.byref(job.ws), _lib.stream_ptr(self.device))
+                                         _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(noise),
+                                         _lib.ptr(mods), _lib.ptr(coef), T, C.byref(job.ws),
+                                         _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_sample_loop")
         return x
 

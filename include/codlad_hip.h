@@ -131,12 +131,19 @@ typedef struct {
     float *hE;      /* [n_nodes][64][128]             */
 } codlad_workspace;
 
+/* Step- and member-invariant part of encoder layer 0: E1[0] = W1[:,128:256] @ h_E0 (message) and
+ * E1[1] = W11[:,128:256] @ h_E0 (edge update) per structure edge, E1 [2][n_snodes][64][128].
+ * Optional: passing E1 = NULL below makes the layer-0 kernels contract h_E0 themselves. */
+int codlad_layer0_edge_terms(const codlad_denoiser_weights *w, const int32_t *snode_info,
+                             int n_snodes, const float *h_E0, float *E1, void *stream);
+
 /* Rows 5-7: one denoiser forward (latent_model.py:175-268): x [n_nodes][3] -> out [n_nodes][6].
- * mods_t = the 6016 modulation floats of this timestep. */
+ * mods_t = the 6016 modulation floats of this timestep.  E1 (may be NULL) from
+ * codlad_layer0_edge_terms, n_snodes = its structure-node count. */
 int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                             int n_nodes, const int32_t *E_idx, const float *h_E0,
-                            const float *x, const float *mods_t, float *out,
-                            const codlad_workspace *ws, void *stream);
+                            const float *E1, int n_snodes, const float *x, const float *mods_t,
+                            float *out, const codlad_workspace *ws, void *stream);
 
 /* Row 2: one reverse step given the model output (gaussian_diffusion.py:404-449, 262-360).
  * coef_host[8] = {sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2,
@@ -149,8 +156,8 @@ int codlad_ddpm_update(const float *x, const float *model_out, const float *nois
  * loop order (entry 0 at step T-1).  mods [T][6016] and coef [T][8] (device) are indexed by
  * respaced step i; the loop runs i = T-1 .. 0. */
 int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_t *node_info, int n_nodes,
-                       const int32_t *E_idx, const float *h_E0, float *x, const float *noise,
-                       const float *mods, const float *coef, int T,
+                       const int32_t *E_idx, const float *h_E0, const float *E1, int n_snodes,
+                       float *x, const float *noise, const float *mods, const float *coef, int T,
                        const codlad_workspace *ws, void *stream);
 
 /* Row 8: get_norm_feature(norm_in=False) + nearest code
@@ -203,12 +210,14 @@ int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *order
                      void *stream);
 
 /* Measurement hook: ONE launch of the message kernel (which = 0) or the edge-update kernel
- * (which = 1) of encoder layer 0 on a job whose workspace holds the state of a previous forward.
- * Idempotent (reads h_E0, P, Q; writes S or hE).  Used by bench.py to time the dominant kernel. */
+ * (which = 1) of encoder layer `layer` (0 or 1) on a job whose workspace holds the state of a
+ * previous forward; both GEMM layers are executed (no E1 shortcut).  Layer 0 reads the shared h_E0,
+ * layer 1 the per-sample edge state (the HBM-resident case that 5 of a step's 6 message launches are).
+ * Used by bench.py to time the dominant kernel. */
 int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *node_info,
                              int n_nodes, const int32_t *E_idx, const float *h_E0,
                              const float *mods_t, const codlad_workspace *ws, int which,
-                             void *stream);
+                             int layer, void *stream);
 
 /* Self-test of the MFMA chain primitive: Y[n][:] = act(W @ X[n][:] + bias), n < 32*tiles.
  * act: 0 = none, 1 = exact-erf GELU. */

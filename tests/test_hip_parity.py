@@ -192,6 +192,33 @@ def test_ensemble_members_share_structure(den, sd):
     assert torch.equal(o1, o2)
 
 
+def test_hoisted_layer0_edge_terms(den, sd):
+    """The per-structure precomputation of encoder layer 0's edge contractions (E1) holds
+    W1[:,128:256] @ h_E0 / W11[:,128:256] @ h_E0, and using it changes the forward only by rounding
+    (fp32 summation order: P + Q + E1 instead of accumulating onto P + Q)."""
+    pa = synth.make_protein(40, 5, n_frames=1)    # K = 40: one full and one partial column half
+    pb = synth.make_protein(87, 6, n_frames=1)
+    za, zb = torch.from_numpy(pa["z_full"])[1:-1], torch.from_numpy(pb["z_full"])[1:-1]
+    xa, xb = torch.from_numpy(pa["xyz_full"])[0, 1:-1], torch.from_numpy(pb["xyz_full"])[0, 1:-1]
+    st = den.prepare_structures([xa, xb], [za, zb])
+    assert st.E1 is not None and tuple(st.E1.shape) == (2, 127, 64, 128)
+    K = torch.tensor([40] * 40 + [64] * 87, device=DEV)
+    valid = (torch.arange(64, device=DEV)[None, :] < K[:, None])
+    hE = st.h_E0.double()
+    for which, name in enumerate(["W1", "W11"]):
+        W = sd[f"encoder_layers.0.{name}.weight"][:, 128:256].to(DEV).double()
+        want = hE @ W.T
+        got = st.E1[which].double()
+        err = ((got - want).abs() * valid[..., None]).max() / want.abs().max()
+        assert float(err) < 2e-6, (name, float(err))
+    plain = den.prepare_structures([xa, xb], [za, zb], hoist_layer0=False)
+    assert plain.E1 is None
+    x = synth.gaussian((40 + 87 + 87, 3), 99).to(DEV)
+    o_h = den.forward(den.make_job(st, [0, 1, 1]), x, 700)
+    o_p = den.forward(den.make_job(plain, [0, 1, 1]), x, 700)
+    assert rel_err(o_h, o_p) < 2e-6
+
+
 def test_ragged_job_matches_separate_jobs(den, sd):
     """Mixed lengths in one launch (no padding) == each length on its own."""
     pa = synth.make_protein(46, 12, n_frames=1)
