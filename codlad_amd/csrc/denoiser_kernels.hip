@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
         tile_load_row(acc, Prow, h);
         tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
         if (a.E1) {   // layer-1 edge term precomputed per structure (step- and member-invariant)
-            tile_add_row(acc, a.E1 + ((size_t)src * 64 + colc) * HD, h);
+            tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
         } else {
-            tile_load_row(x, rows + (size_t)colc * HD, h);
+            tile_load_edge(x, rows, colc, h);
             gemm128(acc, x, a.W1, lane);
         }
         tile_gelu(acc);
@@ -81,10 +81,10 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
         } else {
             tile_load_row(acc, a.b3, h);
             gemm128(acc, x, a.W3, lane);
-            tile_add_row(acc, rows + (size_t)colc * HD, h);  // residual: h_E + message
+            tile_add_edge(acc, rows, colc, h);  // residual: h_E + message
             tile_layernorm(acc, 1e-6f);
             tile_modulate(acc, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);
-            if (valid) tile_store_row(acc, a.hE_out + ((size_t)n * 64 + col) * HD, h);
+            if (valid) tile_store_edge(acc, a.hE_out + (size_t)n * EDGE_BLOCK, col, h);
         }
     }
 }
@@ -114,12 +114,26 @@ DEV void tile_colsum(Tile &t, bool valid) {
         for (int p = 0; p < 4; ++p) tile_colsum_pair(t, ks, p, valid);
 }
 
+// Small wave-uniform vectors (the centre node's P row, biases, modulation) are NOT read with
+// per-lane global loads: a 128-float vector costs 16 dwordx4 instructions per lane whatever the
+// addresses, and eight of those per tile were half of the kernel's traffic through the texture
+// addresser (tools/ablate_edge.py).  They sit in LDS instead and are read as broadcasts.
+//   LDS (16-byte words): [W1 4096][W2 4096][W3 first W3_KS k-steps][consts 5 x 32][P slots NWAVES x 32]
+constexpr int EDGE_W3_KS = 3;                             // k-steps of W13 that fit in LDS
+constexpr int EDGE_CONST_U4 = 5 * 32;                     // b2, b3, shift3, scale3, gate3
+template <bool EDGE_UPDATE, int NWAVES>
+constexpr int edge_lds_u4() {
+    return 2 * LDS_BLOCK_U4 + (EDGE_UPDATE ? EDGE_W3_KS * 512 : 0) + EDGE_CONST_U4 + NWAVES * 32;
+}
+
 // HOISTED: encoder layer 0 with a.E1 given - layer 1's edge contraction comes precomputed.
 template <bool EDGE_UPDATE, int NWAVES, bool HOISTED = false>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
     constexpr int NT = NWAVES * 64;
+    constexpr int W3_U4 = EDGE_UPDATE ? EDGE_W3_KS * 512 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32x4 *consts = wl + 2 * LDS_BLOCK_U4 + W3_U4;
     {
         const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
         const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
@@ -129,22 +143,32 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
         }
         if (EDGE_UPDATE) {
             const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.W3h);
-            for (int i = tid; i < LDS_BLOCK_U4 / 2; i += NT) wl[2 * LDS_BLOCK_U4 + i] = g3[i];
+            for (int i = tid; i < W3_U4; i += NT) wl[2 * LDS_BLOCK_U4 + i] = g3[i];
+        }
+        if (tid < 32) consts[tid] = reinterpret_cast<const u32x4 *>(a.b2)[tid];
+        if (EDGE_UPDATE && tid >= 64 && tid < 64 + 4 * 32) {
+            const int v = (tid - 64) >> 5, i = tid & 31;      // b3, then shift3 | scale3 | gate3 (contiguous)
+            consts[32 + 32 * v + i] = v == 0 ? reinterpret_cast<const u32x4 *>(a.b3)[i]
+                                             : reinterpret_cast<const u32x4 *>(a.mods3)[32 * (v - 1) + i];
         }
     }
     __syncthreads();
     const u32x4 *w1 = wl, *w2 = wl + LDS_BLOCK_U4, *w3 = wl + 2 * LDS_BLOCK_U4;
+    const float *c_base = reinterpret_cast<const float *>(consts);
+    float *Pslot = reinterpret_cast<float *>(consts + EDGE_CONST_U4 + wave * 32);
     const int h = lane >> 5, c = lane & 31;
     for (int n = blockIdx.x * NWAVES + wave; n < a.n_nodes; n += gridDim.x * NWAVES) {
         const int4 info = a.node_info[n];
         const int src = info.x, base = info.y, K = info.z;
         const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * (64 * HD);
-        const float *Prow = a.P + (size_t)n * HD;
         float *out_rows = EDGE_UPDATE ? a.hE_out + (size_t)n * (64 * HD) : nullptr;
         const bool two = K > 32;                      // wave-uniform
         const bool validA = c < K, validB = 32 + c < K;
         const int colA = validA ? c : 0, colB = validB ? 32 + c : 0;
         const int jA = a.E_idx[(size_t)src * 64 + colA], jB = a.E_idx[(size_t)src * 64 + colB];
+        // this node's P row: one coalesced 512-byte read, staged in the wave's own LDS slot
+        // (same wave writes and reads: program order + lgkmcnt, no barrier)
+        reinterpret_cast<float2 *>(Pslot)[lane] = reinterpret_cast<const float2 *>(a.P + (size_t)n * HD)[lane];
 
         Tile sum;   // message: column sums of the node's first half
         for (int half = 0; half < 2; ++half) {
@@ -153,16 +177,22 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
             const int colc = half ? colB : colA, col = 32 * half + c;
             const int j = half ? jB : jA;
             Tile x, acc, t2;
-            tile_load_row(acc, Prow, h);
-            tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);
+            // the constants never change, so the compiler would read them once, before the node
+            // loop, into ~300 registers and spill those; an opaque zero offset keeps the reads here
+            int lds_off = 0;
+            asm volatile("" : "+v"(lds_off));
+            const float *c_b2 = c_base + lds_off, *c_b3 = c_b2 + HD;
+            const float *c_shift = c_b2 + 2 * HD, *c_scale = c_b2 + 3 * HD, *c_gate = c_b2 + 4 * HD;
+            tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);
+            tile_add_row(acc, Pslot, h);
             if (HOISTED) {   // layer-1 edge term precomputed per structure (step- and member-invariant)
-                tile_add_row(acc, a.E1 + ((size_t)src * 64 + colc) * HD, h);
-                if (EDGE_UPDATE) tile_load_row(x, rows + (size_t)colc * HD, h);   // residual
+                tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
+                if (EDGE_UPDATE) tile_load_edge(x, rows, colc, h);   // residual
             } else {
-                tile_load_row(x, rows + (size_t)colc * HD, h);
+                tile_load_edge(x, rows, colc, h);
                 gemm128_h_lds<false>(acc, x, w1, lane);      // layer 1
             }
-            tile_load_row(t2, a.b2, h);
+            tile_load_row(t2, c_b2, h);
             gemm128_h_lds<true>(t2, acc, w2, lane);          // layer 2 on GELU(layer 1), GELU under the MFMAs
             if (!EDGE_UPDATE) {
                 tile_gelu(t2);
@@ -177,12 +207,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
             } else {
                 // layer 3 accumulates onto h_E + b13: the input tile stays in registers for the
                 // residual instead of being fetched from HBM a second time
-                tile_add_row(x, a.b3, h);
-                gemm_h_lds<0, 4, true>(x, t2, w3, lane);       // layer 3 on GELU(layer 2)
-                gemm_h_glb<4, 4, true>(x, t2, a.W3h, lane);
+#ifdef CODLAD_RESIDUAL_RELOAD
+                tile_load_row(x, c_b3, h);
+                gemm_h_lds<0, EDGE_W3_KS, true>(x, t2, w3, lane);       // layer 3 on GELU(layer 2)
+                gemm_h_glb<EDGE_W3_KS, 8 - EDGE_W3_KS, true>(x, t2, a.W3h, lane);
+                tile_add_edge(x, rows, colc, h);
+#else
+                tile_add_row(x, c_b3, h);
+                gemm_h_lds<0, EDGE_W3_KS, true>(x, t2, w3, lane);       // layer 3 on GELU(layer 2)
+                gemm_h_glb<EDGE_W3_KS, 8 - EDGE_W3_KS, true>(x, t2, a.W3h, lane);
+#endif
                 tile_layernorm(x, 1e-6f);
-                tile_modulate(x, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);
-                if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);
+                tile_modulate(x, c_shift, c_scale, c_gate, h);
+                if (valid) tile_store_edge(x, out_rows, col, h);
             }
         }
     }
@@ -553,8 +590,9 @@ static int num_cu() {
 static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st) {
     if (precision == 1) {
         static bool attr_set = false;
-        const size_t lds_msg = 2 * 65536, lds_upd = 2 * 65536 + 32768;
         constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
+        const size_t lds_msg = 16 * edge_lds_u4<false, MSG_WAVES>(), lds_upd = 16 * edge_lds_u4<true, UPD_WAVES>();
+        static_assert(16 * edge_lds_u4<true, UPD_WAVES>() <= 160 * 1024, "edge update kernel exceeds the CU's LDS");
         if (!attr_set) {
             const void *msg[2] = {reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES, false>),
                                   reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES, true>)};
@@ -789,14 +827,14 @@ __global__ __launch_bounds__(256, 1) void layer0_kernel(Layer0Args a) {
         const bool valid = col < K;
         const int colc = valid ? col : 0;
         Tile x;
-        tile_load_row(x, a.hE0 + ((size_t)m * 64 + colc) * HD, h);
+        tile_load_edge(x, a.hE0 + (size_t)m * EDGE_BLOCK, colc, h);
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
             Tile acc;
             tile_zero(acc);
             if (F16X4) gemm_h_glb<0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane);
             else gemm128(acc, x, which ? a.W_upd : a.W_msg, lane);
-            if (valid) tile_store_row(acc, a.E1 + (((size_t)which * a.n_snodes + m) * 64 + col) * HD, h);
+            if (valid) tile_store_edge(acc, a.E1 + ((size_t)which * a.n_snodes + m) * EDGE_BLOCK, col, h);
         }
     }
 }

@@ -25,6 +25,12 @@ def _require_cuda(t, what):
         raise RuntimeError(f"{what} must live on the GPU: this path has no CPU implementation")
 
 
+def edge_rows(blocks):
+    """Edge state as the kernels keep it in HBM ([..., 32 chunks, 64 edges, 4], include/codlad_hip.h)
+    -> [..., 64 edges, 128 features]."""
+    return blocks.transpose(-3, -2).reshape(*blocks.shape[:-3], blocks.shape[-2], -1)
+
+
 class Structures:
     """Flat structure-node arrays + the step-invariant graph/features of every structure."""
 
@@ -42,7 +48,7 @@ class Structures:
         self.snode_info = torch.from_numpy(info).to(device)
         self.E_idx = None
         self.h_E0 = None
-        self.E1 = None        # [2][n_snodes][64][128]: hoisted layer-0 edge terms (optional)
+        self.E1 = None        # [2] x edge blocks: hoisted layer-0 edge terms (optional)
 
 
 class Job:
@@ -99,14 +105,14 @@ class Denoiser:
         which are the same in every step and for every ensemble member (costs 2x the h_E0 memory)."""
         st = Structures(xyz_list, z_list, self.device)
         st.E_idx = torch.empty(st.n_snodes, KNN, dtype=torch.int32, device=self.device)
-        st.h_E0 = torch.empty(st.n_snodes, KNN, H, dtype=torch.float32, device=self.device)
+        st.h_E0 = torch.empty(st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
         rc = self.lib.codlad_features_prepass(C.byref(self.weights.struct), _lib.ptr(st.xyz),
                                               _lib.ptr(st.snode_info), st.n_snodes, max(st.lens),
                                               _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
                                               _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_features_prepass")
         if hoist_layer0:
-            st.E1 = torch.empty(2, st.n_snodes, KNN, H, dtype=torch.float32, device=self.device)
+            st.E1 = torch.empty(2, st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
             rc = self.lib.codlad_layer0_edge_terms(C.byref(self.weights.struct), _lib.ptr(st.snode_info),
                                                    st.n_snodes, _lib.ptr(st.h_E0), _lib.ptr(st.E1),
                                                    _lib.stream_ptr(self.device))

@@ -111,7 +111,11 @@ typedef struct {
 /* Row 4: CA_ProteinFeatures.forward + W_e
  * (reference models/protein_mpnn_utils.py:478-523, latent_model.py:208,216).
  * snode_info[m] = {start, L} of the structure that structure-node m belongs to.
- * Writes E_idx [n_snodes][64] (ascending distance, self first) and h_E0 [n_snodes][64][128]. */
+ * Writes E_idx [n_snodes][64] (ascending distance, self first) and h_E0, one EDGE BLOCK per
+ * structure node.  An edge block holds 64 edges x 128 features "chunk-major",
+ * [32 chunks of 4 features][64 edges][4 floats] (feature f of edge e at 256*(f/4) + 4*e + f%4), so
+ * that the 16 bytes neighbouring lanes (edges) move per instruction are neighbours in memory; slots
+ * of edges e >= K are never written.  E1 and the workspace's hE use the same block layout. */
 int codlad_features_prepass(const codlad_denoiser_weights *w, const float *cg_xyz,
                             const int32_t *snode_info, int n_snodes, int max_len,
                             int32_t *E_idx, float *h_E0, void *stream);
@@ -128,11 +132,11 @@ typedef struct {
     float *hVenc;   /* [n_nodes][128]                 */
     float *S;       /* [n_nodes][128]                 */
     float *PQ;      /* [4][n_nodes][128]              */
-    float *hE;      /* [n_nodes][64][128]             */
+    float *hE;      /* [n_nodes] edge blocks (64 x 128) */
 } codlad_workspace;
 
 /* Step- and member-invariant part of encoder layer 0: E1[0] = W1[:,128:256] @ h_E0 (message) and
- * E1[1] = W11[:,128:256] @ h_E0 (edge update) per structure edge, E1 [2][n_snodes][64][128].
+ * E1[1] = W11[:,128:256] @ h_E0 (edge update) per structure edge, E1 [2][n_snodes] edge blocks.
  * Optional: passing E1 = NULL below makes the layer-0 kernels contract h_E0 themselves. */
 int codlad_layer0_edge_terms(const codlad_denoiser_weights *w, const int32_t *snode_info,
                              int n_snodes, const float *h_E0, float *E1, void *stream);

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from codlad_amd import _lib, synth
+from codlad_amd import _lib, engine, synth
 from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
 from codlad_amd.engine import Decoder, Denoiser
 from codlad_amd.weights import pack_block
@@ -122,7 +122,7 @@ def test_features_prepass(den, sd, name):
     # compare edge features edge by edge: bring the oracle's rows into this kernel's neighbour order
     perm = (got_idx[..., :, None] == E_idx[..., None, :]).float().argmax(-1)   # [B,L,K]
     hE0 = torch.gather(hE0, 2, perm[..., None].expand(-1, -1, -1, 128))
-    got = st.h_E0.cpu().view(B, L, 64, 128)[:, :, :K]
+    got = engine.edge_rows(st.h_E0).cpu().view(B, L, 64, 128)[:, :, :K]
     # The quaternion features are ill-conditioned by construction in the reference: for the self
     # edge (and any neighbour with a parallel frame) R = O_i^T O_j ~ I and the magnitudes
     # 0.5*sqrt(|1 + Rxx - Ryy - Rzz|) are the square root of rounding noise (~1e-4) with a noise
@@ -201,14 +201,14 @@ def test_hoisted_layer0_edge_terms(den, sd):
     za, zb = torch.from_numpy(pa["z_full"])[1:-1], torch.from_numpy(pb["z_full"])[1:-1]
     xa, xb = torch.from_numpy(pa["xyz_full"])[0, 1:-1], torch.from_numpy(pb["xyz_full"])[0, 1:-1]
     st = den.prepare_structures([xa, xb], [za, zb])
-    assert st.E1 is not None and tuple(st.E1.shape) == (2, 127, 64, 128)
+    assert st.E1 is not None and tuple(engine.edge_rows(st.E1).shape) == (2, 127, 64, 128)
     K = torch.tensor([40] * 40 + [64] * 87, device=DEV)
     valid = (torch.arange(64, device=DEV)[None, :] < K[:, None])
-    hE = st.h_E0.double()
+    hE = engine.edge_rows(st.h_E0).double()
     for which, name in enumerate(["W1", "W11"]):
         W = sd[f"encoder_layers.0.{name}.weight"][:, 128:256].to(DEV).double()
         want = hE @ W.T
-        got = st.E1[which].double()
+        got = engine.edge_rows(st.E1[which]).double()
         err = ((got - want).abs() * valid[..., None]).max() / want.abs().max()
         assert float(err) < 2e-6, (name, float(err))
     plain = den.prepare_structures([xa, xb], [za, zb], hoist_layer0=False)

@@ -1,0 +1,93 @@
+"""Timing-only ablations of the two edge kernels (results of the ablated builds are WRONG on purpose).
+
+    python tools/ablate_edge.py build     # here: patched copies of csrc/ -> variants/libcodlad_<name>.so
+    python tools/ablate_edge.py run       # on the GPU box: time one launch of each kernel per variant
+
+Each variant removes one ingredient of the kernels (a textual patch on a temporary copy of the
+sources), so the difference to `base` is what that ingredient costs in place - which is how the
+"where does the time go" table in DESIGN.md was obtained.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "variants")
+sys.path.insert(0, ROOT)
+
+XLOAD = "tile_load_row(x, rows + (size_t)colc * HD, h);"
+QADD = "tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);"
+# name -> (extra flags, [(file, old, new), ...])
+VARIANTS = {
+    "base": ([], []),
+    "x3": (["-DCODLAD_F16X3"], []),
+    "nogelu": ([], [("common.h", "    if (GELU_IN) {\n        f32x2 t[1] = {x};", "    if (false) {\n        f32x2 t[1] = {x};"),
+                    ("denoiser_kernels.hip", "                tile_gelu(t2);\n                tile_colsum(t2, valid);",
+                     "                tile_colsum(t2, valid);")]),
+    "nosum": ([], [("denoiser_kernels.hip", "                tile_colsum(t2, valid);\n", "")]),
+    "noglb": ([], [("denoiser_kernels.hip", "                gemm_h_glb<4, 4, true>(x, t2, a.W3h, lane);\n", "")]),
+    "noln": ([], [("denoiser_kernels.hip", "                tile_layernorm(x, 1e-6f);\n                tile_modulate(x, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);\n", "")]),
+    "nostore": ([], [("denoiser_kernels.hip", "                if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);",
+                      "                if (valid && x.b[0][0] == 12345.f) tile_store_row(x, out_rows + (size_t)col * HD, h);")]),
+    "noxload": ([], [("denoiser_kernels.hip", XLOAD, "tile_load_row(x, Prow, h);")]),
+    "noq": ([], [("denoiser_kernels.hip", QADD, "tile_add_row(acc, Prow, h);")]),
+    "nomem": ([], [("denoiser_kernels.hip", XLOAD, "tile_load_row(x, Prow, h);"),
+                   ("denoiser_kernels.hip", QADD, "tile_add_row(acc, Prow, h);"),
+                   ("denoiser_kernels.hip", "                if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);",
+                    "                if (valid && x.b[0][0] == 12345.f) tile_store_row(x, out_rows + (size_t)col * HD, h);")]),
+}
+
+
+def build_one(name):
+    flags, patches = VARIANTS[name]
+    tmp = tempfile.mkdtemp(prefix="ablate_" + name)
+    src = os.path.join(tmp, "pkg", "csrc")      # the sources include "../../include/codlad_hip.h"
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+    shutil.copytree(os.path.join(ROOT, "codlad_amd", "csrc"), src, ignore=shutil.ignore_patterns("*.o"))
+    for fn, old, new in patches:
+        p = os.path.join(src, fn)
+        s = open(p).read()
+        n = s.count(old)
+        assert n >= 1, (name, fn, old[:40])
+        open(p, "w").write(s.replace(old, new))
+    from codlad_amd import build as b
+    objs = []
+    for s in b.SOURCES:
+        obj = os.path.join(tmp, s.replace(".hip", ".o"))
+        cmd = [b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include")] + \
+              b.EXTRA_FLAGS.get(s, []) + flags + ["-c", os.path.join(src, s), "-o", obj]
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    lib = os.path.join(OUT, f"libcodlad_{name}.so")
+    subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    shutil.rmtree(tmp)
+    return name
+
+
+def run_one(name):
+    import torch
+    from codlad_amd import _lib
+    _lib.LIB_PATH = os.path.join(OUT, f"libcodlad_{name}.so")
+    import bench
+    w = bench.Workload(torch.device("cuda:0"), 0, "f16x4")
+    w.den.forward(w.job, w.x_T, 500)      # fills the workspace the hook reads
+    t = w.time_dominant_kernel()
+    print(f"{name:10s} message {t['message'] * 1e3:.4f} ms   edge_update {t['edge_update'] * 1e3:.4f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    names = sys.argv[2:] or list(VARIANTS)
+    if mode == "build":
+        os.makedirs(OUT, exist_ok=True)
+        with ThreadPoolExecutor(4) as ex:
+            for n in ex.map(build_one, names):
+                print("built", n, flush=True)
+    elif mode == "run":
+        for n in names:   # one process per variant: a process binds one library
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "run1", n])
+    elif mode == "run1":
+        run_one(names[0])
