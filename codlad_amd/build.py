@@ -15,7 +15,9 @@ SOURCES = ["api.hip", "denoiser_kernels.hip", "features_kernels.hip", "decode_ke
 EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"],
                # SLP packing of the shuffle-reduction adds blocks their fusion into v_add_f32_dpp;
                # the packed math that pays (GELU) is written out explicitly in common.h
-               "denoiser_kernels.hip": ["-fno-slp-vectorize"]}
+               # -fno-honor-nans: min/max on MFMA results otherwise get a canonicalising v_max x,x
+               # each (3 instructions for min(|x|, c)); nothing on this path produces or tests NaN
+               "denoiser_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "codlad_hip.h")]
 
 

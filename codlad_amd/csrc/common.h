@@ -306,30 +306,40 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
     }
 }
 
-// GELU(x) = (0.5 x)(1 + erf(x/sqrt 2)), erf to <= 8.3e-8 absolute (fp32 erf has ulp 6e-8 near 1).
-// Branch-free: with t = min(|x|/sqrt 2, 4),  erfc(t) = exp(-t g(t)),  g a degree-8 minimax fit of
-// -ln(erfc t)/t on [0,4] (coefficients pre-multiplied by -log2 e so one v_exp_f32 finishes it);
-//   x >= 0: 1 + erf = 2 - erfc(t)        x < 0: 1 + erf = erfc(t)   (no cancellation in the tail)
-// 17 VALU instructions against ~45 plus divergent branches for the library erff; end-to-end
-// GELU error 3.9e-7 absolute, the same as evaluating the fp32 formula with a correctly rounded erf.
-// -DCODLAD_EXACT_ERF selects erff() for A/B validation.
+// GELU(x) = x Phi(x) = max(x, 0) - |x| * (erfc(|x|/sqrt 2) / 2), branch-free:
+//   s = min(|x|, 4 sqrt 2),   erfc(s/sqrt 2)/2 = exp2(s g(s) - 1),
+// g a degree-8 minimax fit of log2(erfc t)/t on t in [0,4] re-expressed in s (so neither the
+// 1/sqrt 2 nor the 1/2 costs an instruction; one v_exp_f32 finishes it).  13 VALU instructions
+// (min, 8 fma, fma, exp, max, fma with |.| and - as source modifiers) against ~45 plus divergent
+// branches for the library erff; max absolute error 2.5e-7 over [-8, 8] (fp32 evaluation of the
+// textbook formula with a correctly rounded erf: 2.4e-7), and x * (tiny) keeps full relative
+// accuracy in the negative tail.  -DCODLAD_EXACT_ERF selects erff() for A/B validation.
+#define CODLAD_GELU_C0 5.136640197633824e-07f
+#define CODLAD_GELU_C1 -9.57114389166236e-06f
+#define CODLAD_GELU_C2 7.503479719161987e-05f
+#define CODLAD_GELU_C3 -0.00028452760307118297f
+#define CODLAD_GELU_C4 1.5291185263777152e-05f
+#define CODLAD_GELU_C5 0.006930838339030743f
+#define CODLAD_GELU_C6 -0.05243462696671486f
+#define CODLAD_GELU_C7 -0.4592214822769165f
+#define CODLAD_GELU_C8 -1.1511043310165405f
+#define CODLAD_GELU_CLAMP 5.656854249492381f
 DEV float gelu_erf(float x) {
 #ifdef CODLAD_EXACT_ERF
     return (0.5f * x) * (1.0f + erff(x * 0.70710678118654752440f));
 #else
-    const float t = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
-    float p = 1.1622890269791242e-05f;
-    p = fmaf(p, t, -0.00015313830226659775f);
-    p = fmaf(p, t, 0.000848921830765903f);
-    p = fmaf(p, t, -0.0022762208245694637f);
-    p = fmaf(p, t, 8.650000381749123e-05f);
-    p = fmaf(p, t, 0.02772335335612297f);
-    p = fmaf(p, t, -0.14830751717090607f);
-    p = fmaf(p, t, -0.918442964553833f);
-    p = fmaf(p, t, -1.6279072761535645f);
-    const float e = __builtin_amdgcn_exp2f(p * t);
-    const float w = x >= 0.f ? 2.0f - e : e;
-    return (0.5f * x) * w;
+    const float s = fminf(fabsf(x), CODLAD_GELU_CLAMP);
+    float p = CODLAD_GELU_C0;
+    p = fmaf(p, s, CODLAD_GELU_C1);
+    p = fmaf(p, s, CODLAD_GELU_C2);
+    p = fmaf(p, s, CODLAD_GELU_C3);
+    p = fmaf(p, s, CODLAD_GELU_C4);
+    p = fmaf(p, s, CODLAD_GELU_C5);
+    p = fmaf(p, s, CODLAD_GELU_C6);
+    p = fmaf(p, s, CODLAD_GELU_C7);
+    p = fmaf(p, s, CODLAD_GELU_C8);
+    const float e = __builtin_amdgcn_exp2f(fmaf(p, s, -1.0f));
+    return fmaf(-e, fabsf(x), fmaxf(x, 0.0f));
 #endif
 }
 
@@ -352,44 +362,35 @@ DEV float half_wave_sum(float v) {
     return v;
 }
 
-// GELU on packed fp32 math (v_pk_mul/v_pk_fma), N pairs evaluated side by side so that the
-// dependent Horner steps of one pair are separated by those of the others (a v_pk_fma_f32 that
-// consumes the previous one's result otherwise costs an s_nop): ~19 VALU instructions per pair.
-//   gelu(x) = x * (0.5 + copysign(0.5 - 0.5 erfc(t), x)),  erfc(t) = exp2(t p(t)),  t = min(|x|/sqrt 2, 4)
+// The same on packed fp32 math (v_pk_fma_f32 for the Horner steps), N pairs evaluated side by
+// side so that the dependent steps of one pair are separated by those of the others (a
+// v_pk_fma_f32 that consumes the previous one's result otherwise costs an s_nop).
 template <int N>
 DEV void gelu_pairs(f32x2 (&x)[N]) {
     f32x2 t[N], p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const f32x2 u = x[i] * 0.70710678118654752440f;
-        t[i].x = fminf(fabsf(u.x), 4.0f);
-        t[i].y = fminf(fabsf(u.y), 4.0f);
+        t[i].x = fminf(fabsf(x[i].x), CODLAD_GELU_CLAMP);
+        t[i].y = fminf(fabsf(x[i].y), CODLAD_GELU_CLAMP);
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = t[i] * 1.1622890269791242e-05f + -0.00015313830226659775f;
+    for (int i = 0; i < N; ++i) p[i] = t[i] * CODLAD_GELU_C0 + CODLAD_GELU_C1;
 #define CODLAD_HORNER(c)                     \
     _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + (c);
-    CODLAD_HORNER(0.000848921830765903f)
-    CODLAD_HORNER(-0.0022762208245694637f)
-    CODLAD_HORNER(8.650000381749123e-05f)
-    CODLAD_HORNER(0.02772335335612297f)
-    CODLAD_HORNER(-0.14830751717090607f)
-    CODLAD_HORNER(-0.918442964553833f)
-    CODLAD_HORNER(-1.6279072761535645f)
+    CODLAD_HORNER(CODLAD_GELU_C2)
+    CODLAD_HORNER(CODLAD_GELU_C3)
+    CODLAD_HORNER(CODLAD_GELU_C4)
+    CODLAD_HORNER(CODLAD_GELU_C5)
+    CODLAD_HORNER(CODLAD_GELU_C6)
+    CODLAD_HORNER(CODLAD_GELU_C7)
+    CODLAD_HORNER(CODLAD_GELU_C8)
+    CODLAD_HORNER(-1.0f)
 #undef CODLAD_HORNER
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const f32x2 q = p[i] * t[i];
-        p[i].x = __builtin_amdgcn_exp2f(q.x);
-        p[i].y = __builtin_amdgcn_exp2f(q.y);
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const f32x2 hm = p[i] * -0.5f + 0.5f;   // 0.5 erf(|x|/sqrt 2)
-        f32x2 w;
-        w.x = __builtin_copysignf(hm.x, x[i].x);
-        w.y = __builtin_copysignf(hm.y, x[i].y);
-        x[i] = x[i] * (w + 0.5f);
+        const float ex = __builtin_amdgcn_exp2f(p[i].x), ey = __builtin_amdgcn_exp2f(p[i].y);
+        x[i].x = fmaf(-ex, fabsf(x[i].x), fmaxf(x[i].x, 0.0f));
+        x[i].y = fmaf(-ey, fabsf(x[i].y), fmaxf(x[i].y, 0.0f));
     }
 }
 
