@@ -47,7 +47,7 @@ def algorithmic_flop_per_structure(L):
 class Workload:
     """cfg 2 resident on one GPU."""
 
-    def __init__(self, device, rank, precision="f16x4"):
+    def __init__(self, device, rank, precision="f16x3"):
         from codlad_amd import synth
         from codlad_amd.engine import Decoder, Denoiser
         from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
@@ -179,9 +179,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f16x4", "f32"], default="f16x4",
-                    help="contraction mode: f16x4 = fp16 hi/lo split operands on the f16 matrix pipe with fp32 "
-                         "accumulation (fp32-equivalent, default); f32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--precision", choices=["f16x3", "f16x4", "f32"], default="f16x3",
+                    help="contraction mode: f16x3 (default) / f16x4 = fp32 operands split into fp16 hi+lo halves on "
+                         "the f16 matrix pipe, 3 or 4 cross products per fp32 product, fp32 accumulation "
+                         "(fp32-equivalent); f32 = v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -242,7 +243,7 @@ def main():
     # the committed profile of this same workload (profiles/README.md says how it was taken)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
-    if args.precision == "f16x4" and os.path.exists(tpath):
+    if args.precision != "f32" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
     if rank == 0:
@@ -251,14 +252,15 @@ def main():
         # dominant kernel: layers 1-2 of the encoder message MLP, algorithmic 2*(384*128 + 128*128)
         # FLOP per edge (reference protein_mpnn_utils.py:240-243; W3 runs in the node kernel)
         flop_launch = 2.0 * (384 * 128 + 128 * 128) * wl.n_edges
+        terms = {"f16x3": 3, "f16x4": 4, "f32": 0}[args.precision]
         achieved = flop_launch / kern["message"] / 1e12
         result = {
             "metric": "sampled all-atom structures/sec (100-step DDPM, PED)",
             "value": value, "unit": "structures/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "precision": ("f16x4: fp32 operands split into fp16 hi+lo (|eps| <= 2^-22), 4 f16 MFMAs per product, fp32 "
-                          "accumulate; all other arithmetic fp32" if args.precision == "f16x4" else
+            "precision": (f"{args.precision}: fp32 operands split into fp16 hi+lo (|eps| <= 2^-22), {terms} f16 MFMAs "
+                          "per product, fp32 accumulate; all other arithmetic fp32" if terms else
                           "f32: v_mfma_f32_32x32x2_f32, all arithmetic fp32"),
             "config": {"workload": "cfg2: PED-shaped test set, 4 proteins L=46/87/92/129 x 10 frames x "
                                    "num_ensemble 10 = 400 structures per GPU, 100-step DDPM (mpnn_diffusion) + "
@@ -267,13 +269,13 @@ def main():
                        "edges_per_gpu": wl.n_edges, "ddpm_steps": T_STEPS, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("edge_kernel_h<false> " if args.precision == "f16x4" else "edge_kernel<false> ") +
+                         "kernel": ("msg_kernel_h " if terms else "edge_kernel<false> ") +
                                    "(encoder message MLP, layers 1-2)",
                          "peak_note": "fp32 matrix peak of MI355X_MICROARCH.md; algorithmic FLOP of SURVEY.md 8d "
-                                      "(the kernel executes half of them after the W1 split, and in f16x4 mode "
-                                      "runs them on the f16 pipe), so frac may exceed 1",
-                         "f16_pipe_frac": (4 * 2.0 * 2 * 128 * 128 * wl.n_edges / kern["message"] / 2.5e15
-                                           if args.precision == "f16x4" else None),
+                                      "(the kernel executes half of them after the W1 split, and in the split-fp16 "
+                                      "modes runs them on the f16 pipe), so frac may exceed 1",
+                         "f16_pipe_frac": (terms * 2.0 * 2 * 128 * 128 * wl.n_edges / kern["message"] / 2.5e15
+                                           if terms else None),
                          "launch_ms": kern["message"] * 1e3,
                          "algorithmic_flop_per_launch": flop_launch,
                          "executed_flop_per_launch": 2.0 * 2 * 128 * 128 * wl.n_edges,

@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcodlad_hip.so")
+# CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
+LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
 P = C.c_void_p
 
@@ -80,7 +81,7 @@ _SIGS = {
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, C.c_int, P]),
     "codlad_selftest_gemm128": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
-    "codlad_selftest_gemm128_h": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
+    "codlad_selftest_gemm128_h": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
 }
 
 _lib = None
@@ -99,7 +100,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.codlad_abi_version() != 1:
+        if handle.codlad_abi_version() != 2:
             raise RuntimeError("libcodlad_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -194,14 +194,27 @@ DEV SplitFrag split_frag(const f32x16 &v) {
 
 DEV f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-DEV void mfma_f16x4(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
-    // smallest terms first
-#ifndef CODLAD_F16X3
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.lo, acc, 0, 0, 0);
-#endif
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.lo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.hi, acc, 0, 0, 0);
+// One fp32 product as TERMS fp16 products accumulated in fp32, smallest first:
+//   TERMS = 4: w_lo x_lo + w_lo x_hi + w_hi x_lo + w_hi x_hi            ("f16x4")
+//   TERMS = 3: the w_lo x_lo term (<= 2^-22 |w x|, the size of the split's own representation
+//              error) is dropped: a quarter fewer matrix instructions   ("f16x3", the default)
+// TRANSPOSED swaps the MFMA operands.  The A and B register layouts are mirror images (lane&31 =
+// the m / n index, lane>>5 and the 8 halves = k), so the same two fragments then produce the
+// transposed output block: lane&31 = output feature, registers = the tile's 32 columns (edges).
+template <int TERMS, bool TRANSPOSED = false>
+DEV void mfma_f16(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
+    static_assert(TERMS == 3 || TERMS == 4, "f16x3 or f16x4");
+    if (TRANSPOSED) {
+        if (TERMS == 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.lo, wlo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.hi, wlo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.lo, whi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.hi, whi, acc, 0, 0, 0);
+    } else {
+        if (TERMS == 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, x.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, x.hi, acc, 0, 0, 0);
+    }
 }
 
 // acc += W(128x128, f16x4-packed block in LDS) @ in.  128 f16 MFMAs in 32 groups (k-step, out
@@ -239,7 +252,7 @@ DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
 // scheduling region: inside it the compiler interleaves the VALU instructions with the four
 // MFMAs; across it nothing moves, which keeps register pressure bounded (left alone, hipcc hoists
 // loads and epilogue arithmetic across the whole 128-MFMA block and spills hundreds of registers).
-template <int KS0, int NKS, bool GELU_IN>
+template <int TERMS, int KS0, int NKS, bool GELU_IN, bool TRANSPOSED = false>
 DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
     const u32x4 *w = wl + lane;
     constexpr int G0 = KS0 * 4, NG = NKS * 4;
@@ -260,16 +273,16 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
             ring[(g + 2) % 3][1] = w[((G0 + g + 2) * 2 + 1) * 64];
         }
         if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
-        mfma_f16x4(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
+        mfma_f16<TERMS, TRANSPOSED>(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
         __builtin_amdgcn_sched_barrier(0);
         if (bo == 3) x = xn;
     }
 }
 
 // acc += W @ act(in): GELU_IN applies GELU to `in` on the fly (see split_pair)
-template <bool GELU_IN>
+template <int TERMS, bool GELU_IN, bool TRANSPOSED = false>
 DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
-    gemm_h_lds<0, 8, GELU_IN>(acc, in, wl, lane);
+    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED>(acc, in, wl, lane);
 }
 
 // The same k-step with the weight fragments fetched from global memory (L2-resident) through a
@@ -278,32 +291,50 @@ DEV u32x4 weight_frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, frag_index * 1024, 0));
 }
 
-template <int KS0, int NKS, bool GELU_IN>
-DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wpacked), 0, 65536, 0x00020000);
-    constexpr int G0 = KS0 * 4, NG = NKS * 4;
-    u32x4 ring[4][2];
+// DEPTH = groups in flight.  start() issues the first DEPTH-1 groups' fragment loads and can be
+// called long before run(), so that the L2 latency of a streamed block is paid while the wave does
+// something else (other loads, the LDS-resident part of the same contraction).
+template <int TERMS, int KS0, int NKS, bool GELU_IN, int DEPTH = 4>
+struct StreamedGemm {
+    static constexpr int G0 = KS0 * 4, NG = NKS * 4;
+    static_assert((DEPTH & (DEPTH - 1)) == 0 && DEPTH <= NG, "ring depth: power of two, at most the group count");
+    __amdgpu_buffer_rsrc_t rsrc;
+    u32x4 ring[DEPTH][2];
+
+    DEV void start(const void *Wpacked, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wpacked), 0, 65536, 0x00020000);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        ring[g][0] = weight_frag_load(rsrc, lane, (G0 + g) * 2 + 0);
-        ring[g][1] = weight_frag_load(rsrc, lane, (G0 + g) * 2 + 1);
-    }
-    SplitFrag x, xn;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int ks = KS0 + (g >> 2), bo = g & 3;
-        if (g + 3 < NG) {
-            ring[(g + 3) & 3][0] = weight_frag_load(rsrc, lane, (G0 + g + 3) * 2 + 0);
-            ring[(g + 3) & 3][1] = weight_frag_load(rsrc, lane, (G0 + g + 3) * 2 + 1);
+        for (int g = 0; g < DEPTH - 1; ++g) {
+            ring[g][0] = weight_frag_load(rsrc, lane, (G0 + g) * 2 + 0);
+            ring[g][1] = weight_frag_load(rsrc, lane, (G0 + g) * 2 + 1);
         }
-        if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
-        mfma_f16x4(acc.b[bo], as_f16x8(ring[g & 3][0]), as_f16x8(ring[g & 3][1]), x);
         __builtin_amdgcn_sched_barrier(0);
-        if (bo == 3) x = xn;
     }
+
+    DEV void run(Tile &acc, const Tile &in, int lane) {
+        SplitFrag x, xn;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ks = KS0 + (g >> 2), bo = g & 3;
+            if (g + DEPTH - 1 < NG) {
+                ring[(g + DEPTH - 1) & (DEPTH - 1)][0] = weight_frag_load(rsrc, lane, (G0 + g + DEPTH - 1) * 2 + 0);
+                ring[(g + DEPTH - 1) & (DEPTH - 1)][1] = weight_frag_load(rsrc, lane, (G0 + g + DEPTH - 1) * 2 + 1);
+            }
+            if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
+            mfma_f16<TERMS>(acc.b[bo], as_f16x8(ring[g & (DEPTH - 1)][0]), as_f16x8(ring[g & (DEPTH - 1)][1]), x);
+            __builtin_amdgcn_sched_barrier(0);
+            if (bo == 3) x = xn;
+        }
+    }
+};
+
+template <int TERMS, int KS0, int NKS, bool GELU_IN>
+DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
+    StreamedGemm<TERMS, KS0, NKS, GELU_IN, 4> g;
+    g.start(Wpacked, lane);
+    g.run(acc, in, lane);
 }
 
 // GELU(x) = x Phi(x) = max(x, 0) - |x| * (erfc(|x|/sqrt 2) / 2), branch-free:
@@ -447,6 +478,36 @@ DEV void tile_layernorm(Tile &t, float eps) {
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
         for (int r = 0; r < 16; ++r) t.b[bo][r] *= rstd;
+}
+
+// LayerNorm followed by modulate with the affine form folded: t = (t - mean) * (rstd * A) + B,
+// A = gate (1 + scale), B = gate shift (two vectors instead of three, two VALU per element
+// instead of four; the moments are computed exactly as in tile_layernorm).
+DEV void tile_layernorm_affine(Tile &t, float eps, const float *A, const float *B, int h) {
+    const float mean = column_sum128(tile_own_sum(t)) * (1.0f / 128.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = t.b[bo][r] - mean;
+            t.b[bo][r] = d;
+            v += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(column_sum128(v) * (1.0f / 128.0f) + eps);
+    const float4 *pa = reinterpret_cast<const float4 *>(A);
+    const float4 *pb = reinterpret_cast<const float4 *>(B);
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = 8 * bo + 2 * q + h;
+            const float4 ka = pa[o], kb = pb[o];
+            t.b[bo][4 * q + 0] = fmaf(t.b[bo][4 * q + 0], rstd * ka.x, kb.x);
+            t.b[bo][4 * q + 1] = fmaf(t.b[bo][4 * q + 1], rstd * ka.y, kb.y);
+            t.b[bo][4 * q + 2] = fmaf(t.b[bo][4 * q + 2], rstd * ka.z, kb.z);
+            t.b[bo][4 * q + 3] = fmaf(t.b[bo][4 * q + 3], rstd * ka.w, kb.w);
+        }
 }
 
 // t = gate * (t * (1 + scale) + shift), per-feature vectors of 128 floats (adaLN "modulate")

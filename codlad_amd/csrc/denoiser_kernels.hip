@@ -25,7 +25,7 @@ struct EdgeArgs {
     float *hE_out;         // edge update only
     const float *P, *Q;    // [n_nodes][128]: own-node term (+bias), neighbour term
     const float *W1, *W2, *W3;
-    const void *W1h, *W2h, *W3h;  // f16x4-packed copies (precision 1)
+    const void *W1h, *W2h, *W3h;  // split-fp16 copies (precision 1, 2)
     const float *b2, *b3;
     const float *mods3;    // edge update: shift3, scale3, gate3 (3 x 128)
     float *S;              // message: [n_nodes][128]
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// f16x4 edge kernels (precision 1).  Persistent 512-thread workgroups, one per CU: the two (three)
+// Split-fp16 edge kernels (precision 1 = f16x4, 2 = f16x3).  Persistent 512-thread workgroups, one per CU: the two (three)
 // 64 KB weight blocks of the MLP live in LDS for the whole launch - 128 KB for the message kernel,
 // 160 KB for the edge update (W11e, W12 and the first four k-steps of W13; its last four k-steps
 // stream from L2) - and every wave walks nodes with a grid stride.  The contraction runs on the
@@ -99,70 +99,65 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 // ---------------------------------------------------------------------------------------------
 #define LDS_BLOCK_U4 4096   // one 64 KB packed block in 16-byte words
 
-// masked sum over the wave half's 32 columns of register pair p of k-step slice ks
-DEV void tile_colsum_pair(Tile &t, int ks, int p, bool valid) {
-    f32x16 &blk = t.b[ks >> 1];
-    const int r = (ks & 1) * 8 + 2 * p;
-    blk[r] = half_wave_sum(valid ? blk[r] : 0.f);
-    blk[r + 1] = half_wave_sum(valid ? blk[r + 1] : 0.f);
-}
-
-DEV void tile_colsum(Tile &t, bool valid) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) tile_colsum_pair(t, ks, p, valid);
-}
-
 // Small wave-uniform vectors (the centre node's P row, biases, modulation) are NOT read with
 // per-lane global loads: a 128-float vector costs 16 dwordx4 instructions per lane whatever the
 // addresses, and eight of those per tile were half of the kernel's traffic through the texture
 // addresser (tools/ablate_edge.py).  They sit in LDS instead and are read as broadcasts.
-//   LDS (16-byte words): [W1 4096][W2 4096][W3 first W3_KS k-steps][consts 5 x 32][P slots NWAVES x 32]
-constexpr int EDGE_W3_KS = 3;                             // k-steps of W13 that fit in LDS
-constexpr int EDGE_CONST_U4 = 5 * 32;                     // b2, b3, shift3, scale3, gate3
+//   message LDS (16-byte words): [W1e 4096][W2 4096][consts][P slots NWAVES x 32]
+//   update  LDS                : [W12 4096][W13 4096][W11e first UPD_W1_KS k-steps][consts][P slots]
+// Three blocks do not fit in 160 KB, so the update kernel streams part of ONE block from L2.  That
+// block is W11e, the first contraction of a tile: its fragment loads are issued before the tile's
+// own rows are even requested and run eight groups ahead (the registers are free at that point),
+// which hides the L2 latency that a streamed W13 - needed last, with three tiles live - could not.
+constexpr int UPD_W1_KS = 3;                              // k-steps of W11e that fit in LDS
+constexpr int EDGE_CONST_U4 = 4 * 32;                     // b2, b3, modulate A, modulate B
 template <bool EDGE_UPDATE, int NWAVES>
 constexpr int edge_lds_u4() {
-    return 2 * LDS_BLOCK_U4 + (EDGE_UPDATE ? EDGE_W3_KS * 512 : 0) + EDGE_CONST_U4 + NWAVES * 32;
+    return 2 * LDS_BLOCK_U4 + (EDGE_UPDATE ? UPD_W1_KS * 512 : 0) + EDGE_CONST_U4 + NWAVES * 32;
 }
 
+// Edge update, split-fp16 contractions:
+//   h_E[n,j] <- mod3(LN(h_E[n,j] + W13 GELU(W12 GELU(P_i + Q_j + W11e h_E[n,j]) + b12) + b13))
 // HOISTED: encoder layer 0 with a.E1 given - layer 1's edge contraction comes precomputed.
-template <bool EDGE_UPDATE, int NWAVES, bool HOISTED = false>
-__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArgs a) {
+template <int NWAVES, bool HOISTED, int TERMS>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
     constexpr int NT = NWAVES * 64;
-    constexpr int W3_U4 = EDGE_UPDATE ? EDGE_W3_KS * 512 : 0;
+    constexpr int W1_U4 = UPD_W1_KS * 512;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32x4 *consts = wl + 2 * LDS_BLOCK_U4 + W3_U4;
+    u32x4 *consts = wl + 2 * LDS_BLOCK_U4 + W1_U4;
     {
         const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
         const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
+        const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.W3h);
         for (int i = tid; i < LDS_BLOCK_U4; i += NT) {
-            if (!HOISTED) wl[i] = g1[i];
-            wl[LDS_BLOCK_U4 + i] = g2[i];
+            wl[i] = g2[i];
+            wl[LDS_BLOCK_U4 + i] = g3[i];
         }
-        if (EDGE_UPDATE) {
-            const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.W3h);
-            for (int i = tid; i < W3_U4; i += NT) wl[2 * LDS_BLOCK_U4 + i] = g3[i];
-        }
+        if (!HOISTED)
+            for (int i = tid; i < W1_U4; i += NT) wl[2 * LDS_BLOCK_U4 + i] = g1[i];
         if (tid < 32) consts[tid] = reinterpret_cast<const u32x4 *>(a.b2)[tid];
-        if (EDGE_UPDATE && tid >= 64 && tid < 64 + 4 * 32) {
-            const int v = (tid - 64) >> 5, i = tid & 31;      // b3, then shift3 | scale3 | gate3 (contiguous)
-            consts[32 + 32 * v + i] = v == 0 ? reinterpret_cast<const u32x4 *>(a.b3)[i]
-                                             : reinterpret_cast<const u32x4 *>(a.mods3)[32 * (v - 1) + i];
+        if (tid >= 64 && tid < 96) consts[32 + (tid & 31)] = reinterpret_cast<const u32x4 *>(a.b3)[tid & 31];
+        if (tid >= 128 && tid < 160) {
+            // modulate folded to one multiply-add: A = gate (1 + scale), B = gate shift
+            const float4 *m = reinterpret_cast<const float4 *>(a.mods3);
+            const int i = tid & 31;
+            const float4 s = m[i], c = m[32 + i], g = m[64 + i];
+            float4 *cf = reinterpret_cast<float4 *>(consts);
+            cf[64 + i] = make_float4(g.x * (1.0f + c.x), g.y * (1.0f + c.y), g.z * (1.0f + c.z), g.w * (1.0f + c.w));
+            cf[96 + i] = make_float4(g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w);
         }
     }
     __syncthreads();
-    const u32x4 *w1 = wl, *w2 = wl + LDS_BLOCK_U4, *w3 = wl + 2 * LDS_BLOCK_U4;
+    const u32x4 *w2 = wl, *w3 = wl + LDS_BLOCK_U4, *w1 = wl + 2 * LDS_BLOCK_U4;
     const float *c_base = reinterpret_cast<const float *>(consts);
     float *Pslot = reinterpret_cast<float *>(consts + EDGE_CONST_U4 + wave * 32);
     const int h = lane >> 5, c = lane & 31;
     for (int n = blockIdx.x * NWAVES + wave; n < a.n_nodes; n += gridDim.x * NWAVES) {
         const int4 info = a.node_info[n];
         const int src = info.x, base = info.y, K = info.z;
-        const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * (64 * HD);
-        float *out_rows = EDGE_UPDATE ? a.hE_out + (size_t)n * (64 * HD) : nullptr;
-        const bool two = K > 32;                      // wave-uniform
+        const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * EDGE_BLOCK;
+        float *out_rows = a.hE_out + (size_t)n * EDGE_BLOCK;
         const bool validA = c < K, validB = 32 + c < K;
         const int colA = validA ? c : 0, colB = validB ? 32 + c : 0;
         const int jA = a.E_idx[(size_t)src * 64 + colA], jB = a.E_idx[(size_t)src * 64 + colB];
@@ -170,58 +165,168 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void edge_kernel_h(EdgeArg
         // (same wave writes and reads: program order + lgkmcnt, no barrier)
         reinterpret_cast<float2 *>(Pslot)[lane] = reinterpret_cast<const float2 *>(a.P + (size_t)n * HD)[lane];
 
-        Tile sum;   // message: column sums of the node's first half
         for (int half = 0; half < 2; ++half) {
             if (32 * half >= K) break;
             const bool valid = half ? validB : validA;
             const int colc = half ? colB : colA, col = 32 * half + c;
             const int j = half ? jB : jA;
             Tile x, acc, t2;
+            StreamedGemm<TERMS, UPD_W1_KS, 8 - UPD_W1_KS, false, 8> tail1;
+            if (!HOISTED) tail1.start(a.W1h, lane);
             // the constants never change, so the compiler would read them once, before the node
             // loop, into ~300 registers and spill those; an opaque zero offset keeps the reads here
             int lds_off = 0;
             asm volatile("" : "+v"(lds_off));
             const float *c_b2 = c_base + lds_off, *c_b3 = c_b2 + HD;
-            const float *c_shift = c_b2 + 2 * HD, *c_scale = c_b2 + 3 * HD, *c_gate = c_b2 + 4 * HD;
+            const float *c_modA = c_b2 + 2 * HD, *c_modB = c_b2 + 3 * HD;
             tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);
             tile_add_row(acc, Pslot, h);
-            if (HOISTED) {   // layer-1 edge term precomputed per structure (step- and member-invariant)
+            tile_load_edge(x, rows, colc, h);                          // layer-1 operand and residual
+            if (HOISTED) {
                 tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
-                if (EDGE_UPDATE) tile_load_edge(x, rows, colc, h);   // residual
             } else {
-                tile_load_edge(x, rows, colc, h);
-                gemm128_h_lds<false>(acc, x, w1, lane);      // layer 1
+                gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane);   // layer 1, resident k-steps
+                tail1.run(acc, x, lane);                                    // layer 1, streamed k-steps
             }
             tile_load_row(t2, c_b2, h);
-            gemm128_h_lds<true>(t2, acc, w2, lane);          // layer 2 on GELU(layer 1), GELU under the MFMAs
-            if (!EDGE_UPDATE) {
-                tile_gelu(t2);
-                tile_colsum(t2, valid);
-                if (half == 0) {
-                    sum = t2;
-                } else {
+            gemm128_h_lds<TERMS, true>(t2, acc, w2, lane);             // layer 2 on GELU(layer 1)
+            // layer 3 accumulates onto h_E + b13: the input tile stays in registers for the
+            // residual instead of being fetched from HBM a second time
+            tile_add_row(x, c_b3, h);
+            gemm128_h_lds<TERMS, true>(x, t2, w3, lane);               // layer 3 on GELU(layer 2)
+            tile_layernorm_affine(x, 1e-6f, c_modA, c_modB, h);
+            if (valid) tile_store_edge(x, out_rows, col, h);
+        }
+    }
+}
+
+// Message kernel, split-fp16 contractions: S[n] = sum_j GELU(W2 GELU(P_i + Q_j + W1e h_E[i,j]) + b2) over the K
+// neighbours.  Same LDS residency as edge_kernel_h; on top of that
+//   * the LAST contraction is issued with swapped MFMA operands, so its output block arrives
+//     transposed (lane = feature, registers = the tile's 32 edges): the sum over neighbours is
+//     then 15 register adds per block instead of a 5-step cross-lane reduction per register;
+//   * with the 64-register running sum gone, the next tile's edge rows are fetched while layer 2
+//     runs and its Q rows while the epilogue runs (a wave walks its (node, half) tiles in order).
+template <int NWAVES, bool HOISTED, int TERMS>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs a) {
+    extern __shared__ __align__(16) u32x4 wl[];
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32x4 *consts = wl + 2 * LDS_BLOCK_U4;
+    {
+        const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
+        const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
+        for (int i = tid; i < LDS_BLOCK_U4; i += NT) {
+            if (!HOISTED) wl[i] = g1[i];
+            wl[LDS_BLOCK_U4 + i] = g2[i];
+        }
+        if (tid < 32) consts[tid] = reinterpret_cast<const u32x4 *>(a.b2)[tid];
+    }
+    __syncthreads();
+    const u32x4 *w1 = wl, *w2 = wl + LDS_BLOCK_U4;
+    const float *c_b2 = reinterpret_cast<const float *>(consts);
+    float2 *Pslot = reinterpret_cast<float2 *>(consts + EDGE_CONST_U4 + wave * 32);
+    const int h = lane >> 5, c = lane & 31;
+    const int stride = gridDim.x * NWAVES;
+    int n = blockIdx.x * NWAVES + wave;              // wave-uniform
+    if (n >= a.n_nodes) return;
+
+    const float *xsrc = HOISTED ? a.E1 : a.hE_in;    // layer-1 edge operand: hoisted term or h_E
+    auto block_of = [&](int node, int s) {
+        return xsrc + (size_t)((HOISTED || a.in_by_src) ? s : node) * EDGE_BLOCK;
+    };
+    const float2 *Prows = reinterpret_cast<const float2 *>(a.P);
+
+    int4 info = a.node_info[n];
+    int src = __builtin_amdgcn_readfirstlane(info.x), base = __builtin_amdgcn_readfirstlane(info.y);
+    int K = __builtin_amdgcn_readfirstlane(info.z);
+    int jA = a.E_idx[(size_t)src * 64 + (c < K ? c : 0)];
+    int jB = a.E_idx[(size_t)src * 64 + (32 + c < K ? 32 + c : 0)];
+    Pslot[lane] = Prows[(size_t)n * 64 + lane];
+    int half = 0;
+    Tile x, acc, t2;
+    tile_load_edge(x, block_of(n, src), c < K ? c : 0, h);
+    tile_load_row(acc, a.Q + (size_t)(base + jA) * HD, h);
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    float bias[4];
 #pragma unroll
-                    for (int bo = 0; bo < 4; ++bo) t2.b[bo] += sum.b[bo];
-                }
-                if (c == 31 && (half == 1 || !two)) tile_store_row(t2, a.S + (size_t)n * HD, h);
-            } else {
-                // layer 3 accumulates onto h_E + b13: the input tile stays in registers for the
-                // residual instead of being fetched from HBM a second time
-#ifdef CODLAD_RESIDUAL_RELOAD
-                tile_load_row(x, c_b3, h);
-                gemm_h_lds<0, EDGE_W3_KS, true>(x, t2, w3, lane);       // layer 3 on GELU(layer 2)
-                gemm_h_glb<EDGE_W3_KS, 8 - EDGE_W3_KS, true>(x, t2, a.W3h, lane);
-                tile_add_edge(x, rows, colc, h);
-#else
-                tile_add_row(x, c_b3, h);
-                gemm_h_lds<0, EDGE_W3_KS, true>(x, t2, w3, lane);       // layer 3 on GELU(layer 2)
-                gemm_h_glb<EDGE_W3_KS, 8 - EDGE_W3_KS, true>(x, t2, a.W3h, lane);
-#endif
-                tile_layernorm(x, 1e-6f);
-                tile_modulate(x, c_shift, c_scale, c_gate, h);
-                if (valid) tile_store_edge(x, out_rows, col, h);
+    for (int bo = 0; bo < 4; ++bo) bias[bo] = c_b2[32 * bo + c];
+
+    // the node after this one (kept equal to the current node when there is none, so that the
+    // prefetch below always has a valid address and needs no branch)
+    int4 ninfo = info;
+    int nsrc = src, nbase = base, nK = K, njA = jA, njB = jB;
+    float2 npv = {0.f, 0.f};
+    for (;;) {
+        const int n2 = n + stride;
+        const bool next_node = n2 < a.n_nodes;
+        const bool first_half = half == 0;
+        if (first_half && next_node) ninfo = a.node_info[n2];
+        tile_add_row(acc, reinterpret_cast<const float *>(Pslot), h);
+        if (HOISTED) {
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) acc.b[bo] += x.b[bo];
+        } else {
+            gemm128_h_lds<TERMS, false>(acc, x, w1, lane);      // layer 1
+        }
+        if (first_half && next_node) {                   // next node's neighbour list and P row
+            nsrc = __builtin_amdgcn_readfirstlane(ninfo.x);
+            nbase = __builtin_amdgcn_readfirstlane(ninfo.y);
+            nK = __builtin_amdgcn_readfirstlane(ninfo.z);
+            njA = a.E_idx[(size_t)nsrc * 64 + (c < nK ? c : 0)];
+            njB = a.E_idx[(size_t)nsrc * 64 + (32 + c < nK ? 32 + c : 0)];
+            npv = Prows[(size_t)n2 * 64 + lane];
+        }
+        const bool next_half = first_half && K > 32;
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) {
+            float bv = bias[bo];
+            asm volatile("" : "+v"(bv));   // or the 64 copies are built once, outside the loop, and spilled
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t2.b[bo][r] = bv;
+        }
+        gemm128_h_lds<TERMS, true, true>(t2, acc, w2, lane);    // layer 2 on GELU(layer 1), output transposed
+        {   // edge rows and Q rows of the next tile, in flight during the epilogue
+            const int pn = next_half ? n : (next_node ? n2 : n), ps = next_half ? src : nsrc;
+            const int pe = next_half ? (32 + c < K ? 32 + c : 0) : (c < nK ? c : 0);
+            const int pq = next_half ? base + jB : nbase + njA;
+            tile_load_edge(x, block_of(pn, ps), pe, h);
+            tile_load_row(acc, a.Q + (size_t)pq * HD, h);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile_gelu(t2);
+        const int cnt = K - 32 * half;                   // valid edges of this tile (wave-uniform)
+        if (cnt >= 32) {
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) {
+                float s0 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s0 += t2.b[bo][r];
+                sum[bo] += s0;
+            }
+        } else {
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) {
+                float s0 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s0 += ((r & 3) + 8 * (r >> 2) + 4 * h < cnt) ? t2.b[bo][r] : 0.f;
+                sum[bo] += s0;
             }
         }
+        if (next_half) {
+            half = 1;
+            continue;
+        }
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) {
+            const float tot = sum[bo] + __shfl_xor(sum[bo], 32);
+            if (h == 0) a.S[(size_t)n * HD + 32 * bo + c] = tot;
+            sum[bo] = 0.f;
+        }
+        if (!next_node) break;
+        n = n2; src = nsrc; base = nbase; K = nK; jA = njA; jB = njB;
+        Pslot[lane] = npv;
+        half = 0;
     }
 }
 
@@ -250,7 +355,7 @@ struct NodeArgs {
     const float *hVenc_in;
     float *hVenc_out;                  // if set: also store the new h_V here (h_Venc := h_V)
     int venc_is_self;                  // h_Venc == new h_V (first decoder layer's Q)
-    // precision 1: f16x4 copies of the blocks in execution order: [W3, Win0, Wout0, .., Wout3,] proj0..
+    // precision 1, 2: split-fp16 copies of the blocks in execution order: [W3, Win0, Wout0, .., Wout3,] proj0..
     const void *blk_h[13];
 };
 
@@ -330,13 +435,13 @@ __global__ __launch_bounds__(64, 1) void node_kernel(NodeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// f16x4 node kernel (precision 1).  A workgroup of NW waves owns NW 32-node tiles; the up to 13
+// Split-fp16 node kernel (precision 1, 2).  A workgroup of NW waves owns NW 32-node tiles; the up to 13
 // weight blocks of the node update are streamed through a 2 x 64 KB LDS double buffer: block i+1
 // is fetched from L2 into registers before the waves contract with block i and written to the
 // other buffer after it, one barrier per block.  Every wave of the chip reads each block from L2
 // once per workgroup instead of once per tile.
 // ---------------------------------------------------------------------------------------------
-template <bool MODE_UPD, int NW>
+template <bool MODE_UPD, int NW, int TERMS>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
     constexpr int NT = NW * 64;
@@ -367,8 +472,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
         const bool more = cur + 1 < n_blk;
         if (more) fetch(cur + 1);
         const u32x4 *w = wl + (cur & 1) * LDS_BLOCK_U4;
-        if (gelu_in) gemm128_h_lds<true>(acc, in, w, lane);
-        else gemm128_h_lds<false>(acc, in, w, lane);
+        if (gelu_in) gemm128_h_lds<TERMS, true>(acc, in, w, lane);
+        else gemm128_h_lds<TERMS, false>(acc, in, w, lane);
         if (more) commit(cur + 1);
         __syncthreads();
         ++cur;
@@ -587,55 +692,62 @@ static int num_cu() {
     return g_num_cu;
 }
 
-static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st) {
-    if (precision == 1) {
-        static bool attr_set = false;
-        constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
-        const size_t lds_msg = 16 * edge_lds_u4<false, MSG_WAVES>(), lds_upd = 16 * edge_lds_u4<true, UPD_WAVES>();
-        static_assert(16 * edge_lds_u4<true, UPD_WAVES>() <= 160 * 1024, "edge update kernel exceeds the CU's LDS");
-        if (!attr_set) {
-            const void *msg[2] = {reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES, false>),
-                                  reinterpret_cast<const void *>(edge_kernel_h<false, MSG_WAVES, true>)};
-            const void *upd[2] = {reinterpret_cast<const void *>(edge_kernel_h<true, UPD_WAVES, false>),
-                                  reinterpret_cast<const void *>(edge_kernel_h<true, UPD_WAVES, true>)};
-            for (int i = 0; i < 2; ++i) {
-                (void)hipFuncSetAttribute(msg[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msg);
-                (void)hipFuncSetAttribute(upd[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd);
-            }
-            attr_set = true;
+// precision: 0 = fp32 MFMA, 1 = f16x4, 2 = f16x3 (include/codlad_hip.h)
+template <int TERMS>
+static void launch_edge_h(bool update, const EdgeArgs &ea, hipStream_t st) {
+    static bool attr_set = false;     // one flag per TERMS instantiation
+    constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
+    const size_t lds_msg = 16 * edge_lds_u4<false, MSG_WAVES>(), lds_upd = 16 * edge_lds_u4<true, UPD_WAVES>();
+    static_assert(16 * edge_lds_u4<true, UPD_WAVES>() <= 160 * 1024, "edge update kernel exceeds the CU's LDS");
+    if (!attr_set) {
+        const void *msg[2] = {reinterpret_cast<const void *>(msg_kernel_h<MSG_WAVES, false, TERMS>),
+                              reinterpret_cast<const void *>(msg_kernel_h<MSG_WAVES, true, TERMS>)};
+        const void *upd[2] = {reinterpret_cast<const void *>(upd_kernel_h<UPD_WAVES, false, TERMS>),
+                              reinterpret_cast<const void *>(upd_kernel_h<UPD_WAVES, true, TERMS>)};
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFuncSetAttribute(msg[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msg);
+            (void)hipFuncSetAttribute(upd[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd);
         }
-        const int nw = update ? UPD_WAVES : MSG_WAVES;
-        const int groups = (ea.n_nodes + nw - 1) / nw;
-        dim3 grid(groups < num_cu() ? groups : num_cu()), block(nw * 64);
-        const bool hoisted = ea.E1 != nullptr;
-        if (update && hoisted) hipLaunchKernelGGL((edge_kernel_h<true, UPD_WAVES, true>), grid, block, lds_upd, st, ea);
-        else if (update) hipLaunchKernelGGL((edge_kernel_h<true, UPD_WAVES, false>), grid, block, lds_upd, st, ea);
-        else if (hoisted) hipLaunchKernelGGL((edge_kernel_h<false, MSG_WAVES, true>), grid, block, lds_msg, st, ea);
-        else hipLaunchKernelGGL((edge_kernel_h<false, MSG_WAVES, false>), grid, block, lds_msg, st, ea);
-        return;
+        attr_set = true;
     }
+    const int nw = update ? UPD_WAVES : MSG_WAVES;
+    const int groups = (ea.n_nodes + nw - 1) / nw;
+    dim3 grid(groups < num_cu() ? groups : num_cu()), block(nw * 64);
+    const bool hoisted = ea.E1 != nullptr;
+    if (update && hoisted) hipLaunchKernelGGL((upd_kernel_h<UPD_WAVES, true, TERMS>), grid, block, lds_upd, st, ea);
+    else if (update) hipLaunchKernelGGL((upd_kernel_h<UPD_WAVES, false, TERMS>), grid, block, lds_upd, st, ea);
+    else if (hoisted) hipLaunchKernelGGL((msg_kernel_h<MSG_WAVES, true, TERMS>), grid, block, lds_msg, st, ea);
+    else hipLaunchKernelGGL((msg_kernel_h<MSG_WAVES, false, TERMS>), grid, block, lds_msg, st, ea);
+}
+
+static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st) {
+    if (precision == 2) return launch_edge_h<3>(update, ea, st);
+    if (precision == 1) return launch_edge_h<4>(update, ea, st);
     dim3 grid((ea.n_nodes + 3) / 4), block(256);
     if (update) hipLaunchKernelGGL(edge_kernel<true>, grid, block, 0, st, ea);
     else hipLaunchKernelGGL(edge_kernel<false>, grid, block, 0, st, ea);
 }
 
-static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t st) {
-    if (precision == 1) {
-        constexpr int NW = 4;
-        static bool attr_set = false;
-        const size_t lds = 2 * 65536;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<true, NW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<false, NW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        dim3 grid((na.n_nodes + 32 * NW - 1) / (32 * NW)), block(NW * 64);
-        if (upd) hipLaunchKernelGGL((node_kernel_h<true, NW>), grid, block, lds, st, na);
-        else hipLaunchKernelGGL((node_kernel_h<false, NW>), grid, block, lds, st, na);
-        return;
+template <int TERMS>
+static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
+    constexpr int NW = 4;
+    static bool attr_set = false;
+    const size_t lds = 2 * 65536;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<true, NW, TERMS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<false, NW, TERMS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
     }
+    dim3 grid((na.n_nodes + 32 * NW - 1) / (32 * NW)), block(NW * 64);
+    if (upd) hipLaunchKernelGGL((node_kernel_h<true, NW, TERMS>), grid, block, lds, st, na);
+    else hipLaunchKernelGGL((node_kernel_h<false, NW, TERMS>), grid, block, lds, st, na);
+}
+
+static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t st) {
+    if (precision == 2) return launch_node_h<3>(upd, na, st);
+    if (precision == 1) return launch_node_h<4>(upd, na, st);
     dim3 grid((na.n_nodes + 31) / 32), block(64);
     if (upd) hipLaunchKernelGGL(node_kernel<true>, grid, block, 0, st, na);
     else hipLaunchKernelGGL(node_kernel<false>, grid, block, 0, st, na);
@@ -815,7 +927,7 @@ struct Layer0Args {
     int n_snodes;
 };
 
-template <bool F16X4>
+template <int TERMS>   // 0: fp32 MFMA, 3 / 4: split fp16
 __global__ __launch_bounds__(256, 1) void layer0_kernel(Layer0Args a) {
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -832,7 +944,7 @@ __global__ __launch_bounds__(256, 1) void layer0_kernel(Layer0Args a) {
         for (int which = 0; which < 2; ++which) {
             Tile acc;
             tile_zero(acc);
-            if (F16X4) gemm_h_glb<0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane);
+            if constexpr (TERMS != 0) gemm_h_glb<TERMS, 0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane);
             else gemm128(acc, x, which ? a.W_upd : a.W_msg, lane);
             if (valid) tile_store_edge(acc, a.E1 + ((size_t)which * a.n_snodes + m) * EDGE_BLOCK, col, h);
         }
@@ -847,8 +959,9 @@ extern "C" int codlad_layer0_edge_terms(const codlad_denoiser_weights *w, const 
     a.W_msg = w->enc[0].W1e; a.W_upd = w->enc[0].W11e;
     a.Wh_msg = w->enc_h[0].W1e; a.Wh_upd = w->enc_h[0].W11e;
     dim3 grid((n_snodes + 3) / 4), block(256);
-    if (w->precision == 1) hipLaunchKernelGGL(layer0_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(layer0_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    if (w->precision == 2) hipLaunchKernelGGL(layer0_kernel<3>, grid, block, 0, (hipStream_t)stream, a);
+    else if (w->precision == 1) hipLaunchKernelGGL(layer0_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(layer0_kernel<0>, grid, block, 0, (hipStream_t)stream, a);
     return codlad_check_launch("codlad_layer0_edge_terms");
 }
 
@@ -896,6 +1009,7 @@ __global__ __launch_bounds__(64) void selftest_kernel(const float *Wp, const flo
     if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(64) void selftest_h_kernel(const void *Wh, const float *bias, const float *X,
                                                         int n_rows, int act, float *Y) {
     const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
@@ -904,16 +1018,17 @@ __global__ __launch_bounds__(64) void selftest_h_kernel(const void *Wh, const fl
     Tile in, acc;
     tile_load_row(in, X + (size_t)rc * HD, h);
     tile_load_row(acc, bias, h);
-    if (act) gemm_h_glb<0, 8, true>(acc, in, Wh, lane);    // Y = W gelu(X) + b
-    else gemm_h_glb<0, 8, false>(acc, in, Wh, lane);       // Y = W X + b
+    if (act) gemm_h_glb<TERMS, 0, 8, true>(acc, in, Wh, lane);    // Y = W gelu(X) + b
+    else gemm_h_glb<TERMS, 0, 8, false>(acc, in, Wh, lane);       // Y = W X + b
     if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
 }
 
-extern "C" int codlad_selftest_gemm128_h(const void *W_f16x4, const float *bias, const float *X, int n_rows,
-                                         int act_in, float *Y, void *stream) {
-    CODLAD_REQUIRE(W_f16x4 && bias && X && Y && n_rows > 0, "bad arguments");
-    hipLaunchKernelGGL(selftest_h_kernel, dim3((n_rows + 31) / 32), dim3(64), 0, (hipStream_t)stream,
-                       W_f16x4, bias, X, n_rows, act_in, Y);
+extern "C" int codlad_selftest_gemm128_h(const void *W_split, const float *bias, const float *X, int n_rows,
+                                         int act_in, int terms, float *Y, void *stream) {
+    CODLAD_REQUIRE(W_split && bias && X && Y && n_rows > 0 && (terms == 3 || terms == 4), "bad arguments");
+    dim3 grid((n_rows + 31) / 32), block(64);
+    if (terms == 3) hipLaunchKernelGGL(selftest_h_kernel<3>, grid, block, 0, (hipStream_t)stream, W_split, bias, X, n_rows, act_in, Y);
+    else hipLaunchKernelGGL(selftest_h_kernel<4>, grid, block, 0, (hipStream_t)stream, W_split, bias, X, n_rows, act_in, Y);
     return codlad_check_launch("codlad_selftest_gemm128_h");
 }
 

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import DenoiserWeights, DecoderWeights
+from .weights import DEFAULT_PRECISION, DenoiserWeights, DecoderWeights
 
 H = 128
 KNN = 64
@@ -91,7 +91,7 @@ class Job:
 class Denoiser:
     """mpnn_diffusion on the GPU."""
 
-    def __init__(self, state_dict, device, precision="f16x4"):
+    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")

@@ -120,9 +120,9 @@ class ProteinMPNN_diffusion_new(nn.Module):
         for layer in list(self.encoder_layers) + list(self.decoder_layers) + [self.W_out]:
             nn.init.constant_(layer.adaLN_modulation[-1].weight, 0)
             nn.init.constant_(layer.adaLN_modulation[-1].bias, 0)
-        # contraction mode of the HIP kernels: "f16x4" (default, fp32-equivalent split-fp16 products on
+        # contraction mode of the HIP kernels: "f16x3" (default) / "f16x4" (fp32-equivalent split-fp16 products on
         # the f16 matrix pipe) or "f32" (v_mfma_f32_32x32x2_f32); see DESIGN.md §4
-        self.precision = "f16x4"
+        self.precision = "f16x3"
         self._engine = None
         self._engine_key = None
         self._job_cache = {}

@@ -224,11 +224,12 @@ class Blob:
         return self.data[o:o + n].view(shape)
 
 
-PRECISIONS = {"f32": 0, "f16x4": 1}
+PRECISIONS = {"f32": 0, "f16x4": 1, "f16x3": 2}      # include/codlad_hip.h, codlad_denoiser_weights.precision
+DEFAULT_PRECISION = "f16x3"
 
 
 class DenoiserWeights:
-    def __init__(self, state_dict, device, precision="f16x4"):
+    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION):
         tensors = denoiser_tensors(state_dict)
         tensors.update(denoiser_tensors_h(state_dict))
         self.blob = Blob(tensors, device)

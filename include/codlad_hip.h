@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 1
+#define CODLAD_ABI_VERSION 2
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -71,9 +71,9 @@ typedef struct {
     const float *b1, *b2, *b3, *b_in, *b_out;
 } codlad_dec_layer;
 
-/* f16x4 copies of the 128x128 blocks: each weight split into hi + lo fp16 halves, 64 KB per block in
- * the order [k-step 0..7][out block 0..3][hi,lo][lane 0..63][8 halves] (codlad_amd/csrc/common.h).
- * Used when codlad_denoiser_weights.precision == 1. */
+/* Split-fp16 copies of the 128x128 blocks: each weight split into hi + lo fp16 halves, 64 KB per
+ * block in the order [k-step 0..7][out block 0..3][hi,lo][lane 0..63][8 halves]
+ * (codlad_amd/csrc/common.h).  Used when codlad_denoiser_weights.precision is 1 or 2. */
 typedef struct {
     const void *W1e, *W2, *W3, *W11e, *W12, *W13, *W1a, *W1c, *W11a, *W11c;
     const void *Win[4], *Wout[4];
@@ -100,9 +100,11 @@ typedef struct {
     codlad_enc_layer enc[3];
     codlad_dec_layer dec[3];
     /* 0: contractions on v_mfma_f32_32x32x2_f32 (exact fp32 products);
-     * 1: f16x4 - operands split into two fp16 halves, four f16 MFMAs per product, fp32 accumulate
-     *    (operand representation error <= 2^-22, i.e. fp32-equivalent; 4x fewer matrix cycles and
-     *    they overlap with the fp32 epilogue work). */
+     * 1: f16x4 - both operands split into two fp16 halves (representation error <= 2^-22), the four
+     *    cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate;
+     * 2: f16x3 - the same without the lo x lo product, which is itself <= 2^-22 of the result: a
+     *    quarter fewer matrix instructions at the same measured deviation from mode 0.
+     *    The default of the Python host layer. */
     int precision;
     codlad_enc_layer_h enc_h[3];
     codlad_dec_layer_h dec_h[3];
@@ -228,10 +230,11 @@ int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *no
 int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X, int n_rows,
                             int act, float *Y, void *stream);
 
-/* Same for the f16x4 contraction: Y[n][:] = W @ act_in(X[n][:]) + bias with W packed by the f16x4
- * order (codlad_amd.weights.pack_block_h); act_in: 0 = none, 1 = GELU applied to the input. */
-int codlad_selftest_gemm128_h(const void *W_f16x4, const float *bias, const float *X, int n_rows,
-                              int act_in, float *Y, void *stream);
+/* Same for the split-fp16 contraction: Y[n][:] = W @ act_in(X[n][:]) + bias with W packed in the
+ * split order (codlad_amd.weights.pack_block_h); act_in: 0 = none, 1 = GELU applied to the input;
+ * terms: 4 (f16x4) or 3 (f16x3). */
+int codlad_selftest_gemm128_h(const void *W_split, const float *bias, const float *X, int n_rows,
+                              int act_in, int terms, float *Y, void *stream);
 
 #ifdef __cplusplus
 }

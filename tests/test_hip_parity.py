@@ -30,10 +30,10 @@ def sd():
     return synth.denoiser_state_dict(cases.WEIGHT_SEED)
 
 
-@pytest.fixture(scope="module", params=["f16x4", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x4", "f32"])
 def den(sd, request):
-    """Both contraction modes of the library: f16x4 (default: fp16 hi/lo split operands on the f16
-    matrix pipe, fp32 accumulate) and f32 (v_mfma_f32_32x32x2_f32)."""
+    """All contraction modes of the library: f16x3 (default) and f16x4 (fp16 hi/lo split operands on
+    the f16 matrix pipe, 3 or 4 cross products, fp32 accumulate) and f32 (v_mfma_f32_32x32x2_f32)."""
     return Denoiser(sd, DEV, precision=request.param)
 
 
@@ -67,7 +67,8 @@ def test_mfma_chain_primitive(act):
     assert rel_err(Y, ref) < 2e-6
 
 
-def test_f16x4_chain_primitive_is_exact_on_integers():
+@pytest.mark.parametrize("terms", [3, 4])
+def test_split_f16_chain_primitive_is_exact_on_integers(terms):
     """Operand lane maps of v_mfma_f32_32x32x16_f16 + the hi/lo packing, checked with small integers
     (exact in fp16, so any mapping error shows as a wrong integer, not as rounding)."""
     from codlad_amd.weights import pack_block_h
@@ -78,7 +79,7 @@ def test_f16x4_chain_primitive_is_exact_on_integers():
     X = torch.randint(-16, 17, (77, 128), generator=g).float()
     Y = torch.empty(77, 128, device=DEV)
     Wh, bd, Xd = pack_block_h(W).to(DEV), b.to(DEV), X.to(DEV)
-    rc = _lib.lib().codlad_selftest_gemm128_h(_lib.ptr(Wh), _lib.ptr(bd), _lib.ptr(Xd), 77, 0, _lib.ptr(Y), None)
+    rc = _lib.lib().codlad_selftest_gemm128_h(_lib.ptr(Wh), _lib.ptr(bd), _lib.ptr(Xd), 77, 0, terms, _lib.ptr(Y), None)
     _lib.check(rc, "selftest_h")
     torch.cuda.synchronize()
     assert torch.equal(Y.cpu(), X @ W.t() + b)
@@ -87,7 +88,7 @@ def test_f16x4_chain_primitive_is_exact_on_integers():
     X2 = torch.randn(77, 128, generator=g) * 3.0
     W2h, X2d = pack_block_h(W2).to(DEV), X2.to(DEV)
     for act in (0, 1):
-        rc = _lib.lib().codlad_selftest_gemm128_h(_lib.ptr(W2h), _lib.ptr(bd), _lib.ptr(X2d), 77, act, _lib.ptr(Y), None)
+        rc = _lib.lib().codlad_selftest_gemm128_h(_lib.ptr(W2h), _lib.ptr(bd), _lib.ptr(X2d), 77, act, terms, _lib.ptr(Y), None)
         _lib.check(rc, "selftest_h")
         torch.cuda.synchronize()
         xin = torch.nn.functional.gelu(X2.double()) if act else X2.double()
@@ -268,22 +269,23 @@ def test_stepwise_equals_fused_loop(den, sd):
     assert torch.equal(x, fused)
 
 
-def test_f16x4_agrees_with_f32_mfma_and_survives_large_latents(sd):
-    """The two contraction modes agree to fp32 rounding level, also when the latent is far outside
+def test_split_f16_agrees_with_f32_mfma_and_survives_large_latents(sd):
+    """The contraction modes agree to fp32 rounding level, also when the latent is far outside
     the trained range (|x| ~ 3000, as late steps of an untrained sampler produce): the only
     un-normalised operand, the neighbour sum S, is contracted with a power-of-two pre-scale so its
     fp16 halves do not overflow."""
     L, B, seed = cases.DENOISER_CASES["L87_B2"]
     prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
     outs = {}
-    for prec in ("f32", "f16x4"):
+    for prec in ("f32", "f16x4", "f16x3"):
         d = Denoiser(sd, DEV, precision=prec)
         st = structures_of(d, prot)
         job = d.make_job(st, list(range(B)))
         outs[prec] = [d.forward(job, (x * s).reshape(-1, 3).to(DEV), 500).cpu() for s in (1.0, 30.0, 3000.0)]
-    for a, b in zip(outs["f32"], outs["f16x4"]):
-        assert bool(torch.isfinite(b).all())
-        assert rel_err(b, a) < 5e-6
+    for prec in ("f16x4", "f16x3"):
+        for a, b in zip(outs["f32"], outs[prec]):
+            assert bool(torch.isfinite(b).all())
+            assert rel_err(b, a) < 5e-6
 
 
 def test_deterministic_replay(den, sd):

@@ -18,26 +18,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "variants")
 sys.path.insert(0, ROOT)
 
-XLOAD = "tile_load_row(x, rows + (size_t)colc * HD, h);"
-QADD = "tile_add_row(acc, a.Q + (size_t)(base + j) * HD, h);"
+# Patches on the edge-UPDATE kernel (upd_kernel_h) and, for nogelu, on both kernels.
+XLOAD = "tile_load_edge(x, rows, colc, h);                          // layer-1 operand and residual"
+QLOAD = "tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);"
+STORE = "            if (valid) tile_store_edge(x, out_rows, col, h);"
+NOSTORE = "            if (valid && x.b[0][0] == 12345.f) tile_store_edge(x, out_rows, col, h);"
 # name -> (extra flags, [(file, old, new), ...])
 VARIANTS = {
     "base": ([], []),
-    "x3": (["-DCODLAD_F16X3"], []),
     "nogelu": ([], [("common.h", "    if (GELU_IN) {\n        f32x2 t[1] = {x};", "    if (false) {\n        f32x2 t[1] = {x};"),
-                    ("denoiser_kernels.hip", "                tile_gelu(t2);\n                tile_colsum(t2, valid);",
-                     "                tile_colsum(t2, valid);")]),
-    "nosum": ([], [("denoiser_kernels.hip", "                tile_colsum(t2, valid);\n", "")]),
-    "noglb": ([], [("denoiser_kernels.hip", "                gemm_h_glb<4, 4, true>(x, t2, a.W3h, lane);\n", "")]),
-    "noln": ([], [("denoiser_kernels.hip", "                tile_layernorm(x, 1e-6f);\n                tile_modulate(x, a.mods3, a.mods3 + HD, a.mods3 + 2 * HD, h);\n", "")]),
-    "nostore": ([], [("denoiser_kernels.hip", "                if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);",
-                      "                if (valid && x.b[0][0] == 12345.f) tile_store_row(x, out_rows + (size_t)col * HD, h);")]),
-    "noxload": ([], [("denoiser_kernels.hip", XLOAD, "tile_load_row(x, Prow, h);")]),
-    "noq": ([], [("denoiser_kernels.hip", QADD, "tile_add_row(acc, Prow, h);")]),
-    "nomem": ([], [("denoiser_kernels.hip", XLOAD, "tile_load_row(x, Prow, h);"),
-                   ("denoiser_kernels.hip", QADD, "tile_add_row(acc, Prow, h);"),
-                   ("denoiser_kernels.hip", "                if (valid) tile_store_row(x, out_rows + (size_t)col * HD, h);",
-                    "                if (valid && x.b[0][0] == 12345.f) tile_store_row(x, out_rows + (size_t)col * HD, h);")]),
+                    ("denoiser_kernels.hip", "        tile_gelu(t2);\n", "")]),
+    "noglb": ([], [("denoiser_kernels.hip",
+                    "                tail1.run(acc, x, lane);                                    // layer 1, streamed k-steps\n", "")]),
+    "noln": ([], [("denoiser_kernels.hip", "            tile_layernorm_affine(x, 1e-6f, c_modA, c_modB, h);\n", "")]),
+    "nostore": ([], [("denoiser_kernels.hip", STORE, NOSTORE)]),
+    "noxload": ([], [("denoiser_kernels.hip", XLOAD, "tile_load_row(x, Pslot, h);")]),
+    "noq": ([], [("denoiser_kernels.hip", QLOAD, "tile_load_row(acc, Pslot, h);")]),
+    "nomem": ([], [("denoiser_kernels.hip", XLOAD, "tile_load_row(x, Pslot, h);"),
+                   ("denoiser_kernels.hip", QLOAD, "tile_load_row(acc, Pslot, h);"),
+                   ("denoiser_kernels.hip", STORE, NOSTORE)]),
 }
 
 
@@ -72,7 +71,7 @@ def run_one(name):
     from codlad_amd import _lib
     _lib.LIB_PATH = os.path.join(OUT, f"libcodlad_{name}.so")
     import bench
-    w = bench.Workload(torch.device("cuda:0"), 0, "f16x4")
+    w = bench.Workload(torch.device("cuda:0"), 0, os.environ.get("CODLAD_PRECISION", "f16x3"))
     w.den.forward(w.job, w.x_T, 500)      # fills the workspace the hook reads
     t = w.time_dominant_kernel()
     print(f"{name:10s} message {t['message'] * 1e3:.4f} ms   edge_update {t['edge_update'] * 1e3:.4f} ms", flush=True)

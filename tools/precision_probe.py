@@ -1,4 +1,4 @@
-"""f16x4 vs f32-MFMA vs fp64 oracle on one forward and a 100-step loop (GPU)."""
+"""f16x3 / f16x4 vs f32-MFMA vs the CPU oracle on one forward and a 100-step loop (GPU)."""
 import sys, torch
 sys.path.insert(0, '.')
 from codlad_amd import synth
@@ -14,7 +14,7 @@ cg_z, cg_xyz, m = oden.batch_to_dense(batch)
 ref32 = oden.forward(sd, x, t, cg_xyz, cg_z, mask)
 def rel(a, b): return float((a.double() - b.double()).abs().max() / b.double().abs().max())
 outs = {}
-for prec in ("f32", "f16x4"):
+for prec in ("f32", "f16x4", "f16x3"):
     d = Denoiser(sd, "cuda:0", precision=prec)
     frames = torch.from_numpy(prot["xyz_full"])[:, 1:-1]; z = torch.from_numpy(prot["z_full"])[1:-1]
     st = d.prepare_structures([f for f in frames], [z] * B); job = d.make_job(st, list(range(B)))
@@ -25,5 +25,6 @@ for prec in ("f32", "f16x4"):
     zz, eps = cases.loop_noise(T, B, L, seed)
     outs[prec + "_loop"] = d.sample(job, zz.reshape(-1, 3).cuda(), eps.reshape(T, -1, 3).cuda(), tb).cpu()
     print(prec, "forward vs CPU fp32 oracle:", rel(o, ref32))
-print("forward f16x4 vs f32-MFMA:", rel(outs["f16x4"], outs["f32"]))
-print("100-step loop f16x4 vs f32-MFMA:", rel(outs["f16x4_loop"], outs["f32_loop"]))
+for prec in ("f16x4", "f16x3"):
+    print(f"forward {prec} vs f32-MFMA:", rel(outs[prec], outs["f32"]))
+    print(f"100-step loop {prec} vs f32-MFMA:", rel(outs[prec + "_loop"], outs["f32_loop"]))
