@@ -482,6 +482,17 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
         fetch(0);
         commit(0);
     }
+    // both modulations folded to one multiply-add each (tile_layernorm_affine), kept in LDS behind
+    // the double buffer: A = gate (1 + scale), B = gate shift
+    const float *modAB = reinterpret_cast<const float *>(wl + 2 * LDS_BLOCK_U4);
+    if (MODE_UPD && tid < 64) {
+        const float4 *m = reinterpret_cast<const float4 *>(a.mods) + 96 * (tid >> 5);
+        const int i = tid & 31;
+        const float4 s = m[i], c = m[32 + i], g = m[64 + i];
+        float4 *cf = reinterpret_cast<float4 *>(wl + 2 * LDS_BLOCK_U4) + 64 * (tid >> 5);
+        cf[i] = make_float4(g.x * (1.0f + c.x), g.y * (1.0f + c.y), g.z * (1.0f + c.z), g.w * (1.0f + c.w));
+        cf[32 + i] = make_float4(g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w);
+    }
     __syncthreads();
 
     Tile v;
@@ -515,8 +526,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
         for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
             for (int r = 0; r < 16; ++r) v.b[bo][r] += (t.b[bo][r] * 64.0f) / 30.0f;
-        tile_layernorm(v, 1e-6f);
-        tile_modulate(v, a.mods, a.mods + HD, a.mods + 2 * HD, h);
+        tile_layernorm_affine(v, 1e-6f, modAB, modAB + HD, h);
         tile_load_row(t, a.b_out, h);
 #pragma unroll 1
         for (int ch = 0; ch < 4; ++ch) {
@@ -526,8 +536,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
         }
 #pragma unroll
         for (int bo = 0; bo < 4; ++bo) v.b[bo] += t.b[bo];
-        tile_layernorm(v, 1e-6f);
-        tile_modulate(v, a.mods + 3 * HD, a.mods + 4 * HD, a.mods + 5 * HD, h);
+        tile_layernorm_affine(v, 1e-6f, modAB + 2 * HD, modAB + 3 * HD, h);
     }
     if (valid) {
         tile_store_row(v, a.hV + (size_t)node * HD, h);
@@ -730,9 +739,9 @@ static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStrea
 
 template <int TERMS>
 static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
-    constexpr int NW = 4;
+    constexpr int NW = 4;   // one 32-node tile per SIMD; eight waves (256 VGPRs each) spill ~150 registers
     static bool attr_set = false;
-    const size_t lds = 2 * 65536;
+    const size_t lds = 2 * 65536 + 4 * 512;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<true, NW, TERMS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
