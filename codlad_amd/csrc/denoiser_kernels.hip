@@ -99,6 +99,31 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 // ---------------------------------------------------------------------------------------------
 #define LDS_BLOCK_U4 4096   // one 64 KB packed block in 16-byte words
 
+// XCD-aware node placement.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+// share one, MI355X_MICROARCH.md "Workgroup dispatch"), each with a private 4 MB L2.  The node list
+// is cut into 8 contiguous chunks and chunk b % 8 is served by the workgroups of that residue
+// class, in the node kernel and in both edge kernels alike: the P/Q rows the node kernel writes,
+// the neighbour rows an edge tile gathers (neighbours are nodes of the same sample, i.e. of the
+// same chunk) and the edge state written by one edge kernel and read by the next then stay within
+// one XCD's L2 instead of being pulled into all eight.  Placement is a speed matter only.
+constexpr int NODE_WG_TILE = 128;                         // nodes per node-kernel workgroup (4 waves x 32)
+__host__ __device__ inline int xcd_chunk_nodes(int n_nodes) {
+    const int wg_tiles = (n_nodes + NODE_WG_TILE - 1) / NODE_WG_TILE;
+    return NODE_WG_TILE * ((wg_tiles + 7) / 8);
+}
+
+struct NodeSpan {
+    int first, end, stride;
+};
+// nodes first, first + stride, ... < end for wave `wave` of this workgroup
+DEV NodeSpan wave_node_span(int n_nodes, int nwaves, int wave) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    if (nb % 8) return {b * nwaves + wave, n_nodes, nb * nwaves};
+    const int chunk = xcd_chunk_nodes(n_nodes);
+    const int lo = (b % 8) * chunk, hi = lo + chunk < n_nodes ? lo + chunk : n_nodes;
+    return {lo + (b / 8) * nwaves + wave, hi, (nb / 8) * nwaves};
+}
+
 // Small wave-uniform vectors (the centre node's P row, biases, modulation) are NOT read with
 // per-lane global loads: a 128-float vector costs 16 dwordx4 instructions per lane whatever the
 // addresses, and eight of those per tile were half of the kernel's traffic through the texture
@@ -153,7 +178,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
     const float *c_base = reinterpret_cast<const float *>(consts);
     float *Pslot = reinterpret_cast<float *>(consts + EDGE_CONST_U4 + wave * 32);
     const int h = lane >> 5, c = lane & 31;
-    for (int n = blockIdx.x * NWAVES + wave; n < a.n_nodes; n += gridDim.x * NWAVES) {
+    const NodeSpan span = wave_node_span(a.n_nodes, NWAVES, wave);
+    for (int n = span.first; n < span.end; n += span.stride) {
         const int4 info = a.node_info[n];
         const int src = info.x, base = info.y, K = info.z;
         const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * EDGE_BLOCK;
@@ -227,9 +253,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
     const float *c_b2 = reinterpret_cast<const float *>(consts);
     float2 *Pslot = reinterpret_cast<float2 *>(consts + EDGE_CONST_U4 + wave * 32);
     const int h = lane >> 5, c = lane & 31;
-    const int stride = gridDim.x * NWAVES;
-    int n = blockIdx.x * NWAVES + wave;              // wave-uniform
-    if (n >= a.n_nodes) return;
+    const NodeSpan span = wave_node_span(a.n_nodes, NWAVES, wave);
+    const int stride = span.stride, n_end = span.end;
+    int n = span.first;                              // wave-uniform
+    if (n >= n_end) return;
 
     const float *xsrc = HOISTED ? a.E1 : a.hE_in;    // layer-1 edge operand: hoisted term or h_E
     auto block_of = [&](int node, int s) {
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
     float2 npv = {0.f, 0.f};
     for (;;) {
         const int n2 = n + stride;
-        const bool next_node = n2 < a.n_nodes;
+        const bool next_node = n2 < n_end;
         const bool first_half = half == 0;
         if (first_half && next_node) ninfo = a.node_info[n2];
         tile_add_row(acc, reinterpret_cast<const float *>(Pslot), h);
@@ -449,7 +476,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
     static_assert(LDS_BLOCK_U4 % NT == 0, "block must divide evenly over the workgroup");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
-    const int node = (blockIdx.x * NW + wave) * 32 + c;
+    // workgroup -> 128-node tile: chunk (blockIdx % 8), see wave_node_span; the grid is 8 x tiles per chunk
+    const int wg_tile = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    if (wg_tile * NODE_WG_TILE >= a.n_nodes) return;      // padding of the last chunk (whole workgroup)
+    const int node = (wg_tile * NW + wave) * 32 + c;
     const bool valid = node < a.n_nodes;
     const int nc = valid ? node : a.n_nodes - 1;
     const int4 info = a.node_info[nc];
@@ -749,7 +779,8 @@ static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((na.n_nodes + 32 * NW - 1) / (32 * NW)), block(NW * 64);
+    static_assert(32 * NW == NODE_WG_TILE, "the XCD chunking assumes 128-node workgroup tiles");
+    dim3 grid(8 * (xcd_chunk_nodes(na.n_nodes) / NODE_WG_TILE)), block(NW * 64);
     if (upd) hipLaunchKernelGGL((node_kernel_h<true, NW, TERMS>), grid, block, lds, st, na);
     else hipLaunchKernelGGL((node_kernel_h<false, NW, TERMS>), grid, block, lds, st, na);
 }
