@@ -1,0 +1,75 @@
+"""The whole hot path on a list of independent units, for the full-size tests.
+
+A unit is (protein, frame, ensemble member): the thing SURVEY.md §8e shards over GPUs.  `run_units` runs any
+subset of the units of a configuration as ONE ragged job - noise -> DDPM loop -> VQ -> IC decode -> ic_to_xyz -
+with per-unit noise that depends on the unit's identity only, so that the result of a unit must not depend
+on which other units share its job (the property a multi-GPU run relies on).
+"""
+import numpy as np
+import torch
+
+from codlad_amd import synth
+from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
+from codlad_amd.engine import Decoder, Denoiser
+
+WEIGHT_SEED, VAE_SEED = 1234, 4321
+
+
+class Config:
+    def __init__(self, name, lengths, n_frames, n_ensemble, vae_type, dataname, T=100, seed0=1000, device="cuda:0"):
+        self.name, self.T, self.device = name, T, torch.device(device)
+        self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), self.device)
+        mean, std = synth.norm_stats(dataname, vae_type)
+        self.dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, VAE_SEED), self.device, mean, std)
+        self.tables = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T)))
+        self.proteins = [synth.make_protein(L, seed0 + i, n_frames=n_frames) for i, L in enumerate(lengths)]
+        # unit id -> (protein, frame, member); ids are stable across shardings
+        self.units = [(p, f, m) for p in range(len(lengths)) for f in range(n_frames) for m in range(n_ensemble)]
+        self.lengths = list(lengths)
+
+    def unit_noise(self, u):
+        """x_T [L,3] and step noise [T,L,3] of unit u: a function of the unit id alone."""
+        L = self.lengths[self.units[u][0]]
+        g = torch.Generator(device=self.device)
+        g.manual_seed(42 + u)
+        r = torch.randn(self.T + 1, L, 3, generator=g, device=self.device)
+        return r[0], r[1:]
+
+    def run_units(self, unit_ids):
+        """-> {unit id: (x0 [L,3], idx [L], xyz [n_atoms,3])} (device tensors)."""
+        unit_ids = sorted(unit_ids)
+        # the structures this job needs, each once
+        s_key = sorted({self.units[u][:2] for u in unit_ids})
+        s_of = {k: i for i, k in enumerate(s_key)}
+        xyz_list, z_list = [], []
+        for p, f in s_key:
+            prot = self.proteins[p]
+            xyz_list.append(torch.from_numpy(prot["xyz_full"])[f, 1:-1])
+            z_list.append(torch.from_numpy(prot["z_full"])[1:-1])
+        st = self.den.prepare_structures(xyz_list, z_list)
+        job = self.den.make_job(st, [s_of[self.units[u][:2]] for u in unit_ids])
+        noise = [self.unit_noise(u) for u in unit_ids]
+        x_T = torch.cat([n[0] for n in noise])
+        eps = torch.cat([n[1] for n in noise], dim=1)
+        x0 = self.den.sample(job, x_T, eps, self.tables)
+        idx, zq, _lat = self.dec.vq(x0)
+        ni = job.node_info
+        cg_z = ni[:, 3].contiguous()
+        cg_xyz = st.xyz[ni[:, 0].long()].contiguous()
+        csr = self.dec.build_csr(cg_xyz, job.sample_lens)
+        ic = self.dec.ic_decode(zq, cg_z, cg_xyz, csr=csr)
+        out = {}
+        off = np.concatenate([[0], np.cumsum(job.sample_lens)])
+        for k, u in enumerate(unit_ids):
+            p, f, _m = self.units[u]
+            prot = self.proteins[p]
+            L = prot["n_cg"]
+            a, b = int(off[k]), int(off[k + 1])
+            ca = torch.from_numpy(prot["xyz_full"])[f][None].to(self.device)
+            xyz = self.dec.ic_to_xyz(ca, ic[a:b].view(1, L, 13, 3), prot["info"])[0]
+            out[u] = (x0[a:b], idx[a:b], xyz)
+        return out
+
+
+def same(a, b):
+    return all(torch.equal(x, y) for x, y in zip(a, b))

@@ -1,0 +1,94 @@
+"""BASELINE.json's configurations at their full per-GPU sizes (GPU, through the C ABI).
+
+The oracle cannot run these sizes in seconds, so they are checked through properties that hold at any
+size: replaying a job reproduces it bit for bit; a unit's result does not depend on which other units
+share its job (the fact the multi-GPU sharding of SURVEY.md §8e rests on), checked bit for bit between
+the whole job and the shards `codlad_amd.parallel.shard_units` deals; code indices are in range and are
+fixed points of the lookup; and a few units of each job are sampled against the CPU oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from codlad_amd import parallel, synth
+from oracle import denoiser as oden
+from oracle import sampler as osam
+from tests import pipeline
+
+pytestmark = pytest.mark.gpu
+
+PED_LENGTHS = [46, 87, 92, 129]
+
+
+def atlas_like_lengths(n, seed=7):
+    """Synthetic stand-in for the `seqlen` column of the Atlas test list (39..505, median ~155)."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    L = np.clip(np.exp(r.normal(np.log(155.0), 0.55, n)), 39, 505).astype(int)
+    L[0], L[1] = 39, 505
+    return [int(x) for x in L]
+
+
+def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=()):
+    whole = cfg.run_units(unit_ids)
+    again = cfg.run_units(unit_ids)
+    for u in unit_ids:                               # deterministic replay
+        assert pipeline.same(whole[u], again[u]), u
+    costs = [parallel.unit_cost(cfg.lengths[cfg.units[u][0]]) for u in unit_ids]
+    shards = parallel.shard_units(costs, n_shards)
+    assert sorted(i for s in shards for i in s) == list(range(len(unit_ids)))
+    for r in shards_to_run:                          # sharding invariance, bit for bit
+        ids = [unit_ids[i] for i in shards[r]]
+        part = cfg.run_units(ids)
+        for u in ids:
+            assert pipeline.same(whole[u], part[u]), (r, u)
+    cb = cfg.dec.weights.codebook
+    for u in unit_ids[:: max(1, len(unit_ids) // 50)]:
+        x0, idx, xyz = whole[u]
+        assert bool(torch.isfinite(x0).all()) and bool(torch.isfinite(xyz).all())
+        assert int(idx.min()) >= 0 and int(idx.max()) < cb.shape[0]
+        idx2, zq2, _ = cfg.dec.vq(cb[idx], normalised=False)      # codes are fixed points of the lookup
+        assert torch.equal(idx2, idx) and torch.equal(zq2, cb[idx])
+    for u in oracle_units:                           # a unit against the CPU oracle, same noise
+        p, f, _m = cfg.units[u]
+        prot = cfg.proteins[p]
+        batch = synth.make_batch(prot, frame_ids=[f])
+        cg_z, cg_xyz, mask = oden.batch_to_dense(batch)
+        x_T, eps = cfg.unit_noise(u)
+        sd = synth.denoiser_state_dict(pipeline.WEIGHT_SEED)
+        ref = osam.p_sample_loop(sd, cfg.T, x_T.cpu()[None], eps.cpu()[:, None], cg_xyz, cg_z, mask,
+                                 hoist_features=True)
+        got = whole[u][0].cpu()
+        err = float((got - ref[0]).abs().max() / ref[0].abs().max())
+        assert err < 1e-4, (u, err)
+    return whole
+
+
+def test_cfg2_ped_n6_full_size():
+    """cfg 2: 4 PED-sized proteins x 10 frames x num_ensemble 10 = 400 structures, 100 steps, N6."""
+    cfg = pipeline.Config("cfg2", PED_LENGTHS, n_frames=10, n_ensemble=10, vae_type="N6", dataname="PED")
+    units = list(range(len(cfg.units)))
+    assert len(units) == 400
+    whole = check_job(cfg, units, n_shards=2, shards_to_run=[0, 1], oracle_units=[0])
+    # ensemble members of one frame differ (different noise) but share one structure
+    assert not torch.equal(whole[0][0], whole[1][0])
+
+
+def test_cfg3_pdb_k3_full_size():
+    """cfg 3: 64 proteins, one frame each, lengths 50-400, angle decoder (K3); all 64 on one GPU and
+    two of the eight per-GPU shards."""
+    lengths = [max(50, min(400, L)) for L in atlas_like_lengths(64, seed=11)]
+    cfg = pipeline.Config("cfg3", lengths, n_frames=1, n_ensemble=1, vae_type="K3", dataname="PDB")
+    check_job(cfg, list(range(64)), n_shards=8, shards_to_run=[0, 5], oracle_units=[int(np.argmin(lengths))])
+
+
+def test_cfg4_atlas_k4_one_gpu_share():
+    """cfg 4: 70 proteins (39..505 residues) x 4 frames x num_ensemble 32 = 8 960 structures over 8 GPUs:
+    the 1 120 structures LPT deals to rank 0, then that share split again."""
+    lengths = atlas_like_lengths(70)
+    cfg = pipeline.Config("cfg4", lengths, n_frames=4, n_ensemble=32, vae_type="K4", dataname="Atlas")
+    assert len(cfg.units) == 8960
+    costs = [parallel.unit_cost(lengths[p]) for p, _f, _m in cfg.units]
+    shards = parallel.shard_units(costs, 8)
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert max(loads) / min(loads) < 1.01            # LPT balance across the 8 ranks
+    check_job(cfg, shards[0], n_shards=2, shards_to_run=[1])
