@@ -61,8 +61,18 @@ class DecoderWeights(C.Structure):
                [(n, P) for n in ("fin1_w", "fin1_b", "fin3_w", "fin3_b")]
 
 
+class MetricInputs(C.Structure):
+    _fields_ = [("xyz_recon", P), ("xyz", P), ("n_atoms", C.c_int64),
+                ("edge_list", P), ("n_edges", C.c_int64), ("clash_list", P), ("n_clash", C.c_int64),
+                ("bb_NO_list", P), ("n_bb", C.c_int64), ("interaction_list", P), ("n_inter", C.c_int64),
+                ("pi_pi_list", P), ("n_pipi", C.c_int64),
+                ("ic", P), ("ic_recon", P), ("ic_mask", P), ("n_ic", C.c_int64)]
+
+
 _SIGS = {
     "codlad_abi_version": (C.c_int, []),
+    "codlad_metrics_scratch_bytes": (C.c_int, []),
+    "codlad_eval_metrics": (C.c_int, [C.POINTER(MetricInputs), P, P, P]),
     "codlad_last_error": (C.c_char_p, []),
     "codlad_struct_sizes": (None, [C.POINTER(C.c_int)]),
     "codlad_pack_block_host": (None, [P, C.c_int, C.c_float, P]),

@@ -225,6 +225,34 @@ int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const int32_t *no
                              const float *mods_t, const codlad_workspace *ws, int which,
                              int layer, void *stream);
 
+/* Next row 8f-2: the evaluation helpers that follow the path in the reference's loop (test.py:589-593):
+ * recon_result (test.py:153-166), xyz_result (:148-151), ged_result (:141-146), clash_result (:118-139),
+ * inter_result (:97-116).  Index lists are int64 as in the reference batch; a list may be empty (NULL, 0).
+ * clash_list = the rows of cat(edge_list, nbr_list) that occur exactly once (the reference derives them
+ * with unique(dim=0, return_counts=True) on every call; they depend on the topology only).
+ * ic / ic_recon [n_ic][3] = (bond, angle, torsion) per slot, ic_mask [n_ic]. */
+typedef struct {
+    const float *xyz_recon, *xyz;      /* [n_atoms][3] */
+    int64_t n_atoms;
+    const int64_t *edge_list;          /* [n_edges][2] */
+    int64_t n_edges;
+    const int64_t *clash_list;         /* [n_clash][2] */
+    int64_t n_clash;
+    const int64_t *bb_NO_list;         /* [n_bb][2] */
+    int64_t n_bb;
+    const int64_t *interaction_list;   /* [n_inter][2] */
+    int64_t n_inter;
+    const int64_t *pi_pi_list;         /* [n_pipi][4] */
+    int64_t n_pipi;
+    const float *ic, *ic_recon, *ic_mask;
+    int64_t n_ic;
+} codlad_metric_inputs;
+
+/* out8 = {loss_bond, loss_angle, loss_torsion, loss_xyz, loss_graph, loss_nbr, loss_inter, loss_pi_pi}
+ * (device floats).  scratch: codlad_metrics_scratch_bytes() of device memory.  Deterministic. */
+int codlad_metrics_scratch_bytes(void);
+int codlad_eval_metrics(const codlad_metric_inputs *in, float *out8, void *scratch, void *stream);
+
 /* Self-test of the MFMA chain primitive: Y[n][:] = act(W @ X[n][:] + bias), n < 32*tiles.
  * act: 0 = none, 1 = exact-erf GELU. */
 int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X, int n_rows,

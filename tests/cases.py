@@ -94,6 +94,58 @@ def decoder_inputs(n_cg, n_frames, seed, vae_type):
     return prot, batch, latent, dataname
 
 
+METRIC_CASES = {
+    # name -> (n_atoms, n_edges, n_nbr_extra, n_bb, n_inter, n_pipi, n_res, seed)
+    "small": (700, 720, 1500, 90, 40, 6, 87, 51),
+    "no_inter": (300, 310, 500, 40, 0, 0, 40, 52),          # empty interaction lists (test.py:101-116 branches)
+    "only_pipi": (300, 310, 500, 40, 0, 5, 40, 53),
+    "big": (40000, 41000, 90000, 5000, 2500, 300, 5000, 54),
+}
+
+
+def metric_inputs(name):
+    """Synthetic stand-ins for what reference test.py:589-593 feeds its metric helpers: reference and
+    reconstructed all-atom coordinates, bond edges, a neighbour list that contains the bond edges plus
+    extra (non-bonded) pairs, backbone N-O pairs, interaction pairs, pi-pi quadruples, and reference /
+    reconstructed internal coordinates with a per-slot mask.  Index lists are random but duplicate-free."""
+    import numpy as np
+    import torch
+    n_atoms, n_edges, n_extra, n_bb, n_inter, n_pipi, n_res, seed = METRIC_CASES[name]
+    r = np.random.Generator(np.random.PCG64(seed))
+    xyz = (r.standard_normal((n_atoms, 3)) * 12.0).astype(np.float32)
+    xyz_recon = (xyz + r.standard_normal((n_atoms, 3)) * 0.4).astype(np.float32)
+
+    def pairs(n, near):
+        """n distinct (i, j), i != j; `near`: partners a few atoms apart, so that some distances fall
+        under the 1.2 A clash threshold once moved closer below"""
+        m = 2 * n + 64
+        i = r.integers(0, n_atoms, m)
+        j = (i + r.integers(1, 6, m)) % n_atoms if near else r.integers(0, n_atoms, m)
+        p = np.unique(np.stack([i, j], 1)[i != j], axis=0)
+        assert len(p) >= n
+        return p[np.sort(r.permutation(len(p))[:n])].astype(np.int64)
+
+    edges = pairs(n_edges, True)
+    cand = pairs(n_extra + n_edges, False)
+    code = lambda p: p[:, 0] * n_atoms + p[:, 1]  # noqa: E731
+    extra = cand[~np.isin(code(cand), code(edges))][:n_extra]
+    nbr = np.concatenate([edges[r.permutation(n_edges)], extra])[r.permutation(n_edges + len(extra))]
+    bb = pairs(n_bb, True)
+    # pull a fifth of the non-bonded and backbone pairs into clash range in the reconstruction
+    for lst in (extra, bb):
+        sel = lst[:: 5]
+        xyz_recon[sel[:, 1]] = xyz_recon[sel[:, 0]] + (r.standard_normal((len(sel), 3)) * 0.5).astype(np.float32)
+    inter = pairs(n_inter, False) if n_inter else np.zeros((0, 2), dtype=np.int64)
+    pipi = r.integers(0, n_atoms, (n_pipi, 4)).astype(np.int64) if n_pipi else np.zeros((0, 4), dtype=np.int64)
+    ic = np.stack([r.uniform(1.0, 1.6, (n_res, 13)), r.uniform(0, np.pi, (n_res, 13)),
+                   r.uniform(-np.pi, np.pi, (n_res, 13))], axis=-1).astype(np.float32)
+    ic_recon = (ic + r.standard_normal(ic.shape) * np.array([0.05, 0.2, 0.6])).astype(np.float32)
+    mask = (r.uniform(size=(n_res * 13,)) < 0.8).astype(np.float32)
+    t = torch.from_numpy
+    return dict(xyz=t(xyz), xyz_recon=t(xyz_recon), edge_list=t(edges), nbr_list=t(nbr), bb_NO_list=t(bb),
+                interaction_list=t(inter), pi_pi_list=t(pipi), ic=t(ic), ic_recon=t(ic_recon), mask=t(mask))
+
+
 def npz_path(name):
     import os
     return os.path.join(os.path.dirname(__file__), "golden", name + ".npz")

@@ -162,3 +162,20 @@ def test_g7_end_to_end_T10(sd):
                                ic.reshape(-1, L, 13, 3), prot["info"])
     rmsd = float(((xyz - torch.from_numpy(gold["xyz"])) ** 2).sum(-1).mean().sqrt())
     assert rmsd < 1e-4
+
+
+@pytest.mark.parametrize("name", list(cases.METRIC_CASES))
+def test_g8_metrics(name):
+    """Evaluation helpers after the path (reference test.py:97-166), incl. empty-list branches."""
+    from oracle import metrics as om
+    gold = np.load(cases.npz_path(f"g8_metrics_{name}"))
+    d = cases.metric_inputs(name)
+    bond, angle, torsion = om.recon_result(d["ic_recon"], d["ic"], d["mask"])
+    inter, pipi = om.inter_result(d["interaction_list"], d["pi_pi_list"], d["xyz_recon"])
+    got = dict(loss_bond=bond, loss_angle=angle, loss_torsion=torsion,
+               loss_xyz=om.xyz_result(d["xyz_recon"], d["xyz"]),
+               loss_graph=om.ged_result(d["xyz_recon"], d["xyz"], d["edge_list"]),
+               loss_nbr=om.clash_result(d["edge_list"], d["nbr_list"], d["xyz_recon"], d["bb_NO_list"]),
+               loss_inter=inter, loss_pi_pi=pipi)
+    for k, v in got.items():
+        assert float(v) == pytest.approx(float(gold[k]), rel=1e-6, abs=1e-9), k

@@ -57,6 +57,7 @@ def install_stubs():
         return out.index_add_(0, index, src)
 
     mod("torch_scatter", scatter_add=scatter_add, scatter_mean=_Missing, scatter=_Missing)
+    mod("torchdiffeq", odeint=_Missing)          # reference test.py:11 (flow sampler, off-path)
 
 
 def quiet(fn, *a, **k):
@@ -73,6 +74,26 @@ def save(name, **arrays):
     path = cases.npz_path(name)
     np.savez_compressed(path, **out)
     print(f"  wrote {os.path.relpath(path, REPO)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------
+def g8_metrics(ref):
+    """The evaluation helpers that follow the path in the reference's loop (test.py:97-166, called at
+    :589-593), run on the synthetic lists of tests/cases.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_test_script", os.path.join(ref["root"], "test.py"))
+    rt = importlib.util.module_from_spec(spec)
+    quiet(spec.loader.exec_module, rt)
+    print("g8 metrics")
+    for name in cases.METRIC_CASES:
+        d = cases.metric_inputs(name)
+        bond, angle, torsion = rt.recon_result(d["ic_recon"], d["ic"], d["mask"])
+        inter, pipi = rt.inter_result(d["interaction_list"], d["pi_pi_list"], d["xyz_recon"])
+        save(f"g8_metrics_{name}", loss_bond=bond, loss_angle=angle, loss_torsion=torsion,
+             loss_xyz=rt.xyz_result(d["xyz_recon"], d["xyz"]),
+             loss_graph=rt.ged_result(d["xyz_recon"], d["xyz"], d["edge_list"]),
+             loss_nbr=rt.clash_result(d["edge_list"], d["nbr_list"], d["xyz_recon"], d["bb_NO_list"]),
+             loss_inter=inter, loss_pi_pi=pipi)
 
 
 # ----------------------------------------------------------------------------
@@ -336,6 +357,7 @@ def main():
     if want("g5"): g5_decoder(ref)
     if want("g6"): g6_ic_to_xyz(ref)
     if want("g7"): g7_end_to_end(ref, model)
+    if want("g8"): g8_metrics(ref)
 
 
 if __name__ == "__main__":
