@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.codlad_abi_version() == 2
+    assert lib.codlad_abi_version() == _lib.ABI_VERSION
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "codlad_hip.h")).read()
+    assert f"#define CODLAD_ABI_VERSION {_lib.ABI_VERSION}\n" in header
 
 
 def test_struct_layouts_match_header():
@@ -156,3 +158,10 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_graft_entry_build_runs_on_cpu():
+    """What the driver runs in the GPU-less container every round: compile (a no-op when up to date),
+    dlopen, resolve every symbol, check the ABI version, import the oracle."""
+    import __graft_entry__
+    __graft_entry__.build()
