@@ -176,22 +176,6 @@ struct SplitFrag {
     f16x8 hi, lo;
 };
 
-// 8 consecutive accumulator registers -> hi/lo fp16 fragments (5 VALU instructions per pair)
-template <int S>
-DEV SplitFrag split_frag(const f32x16 &v) {
-    SplitFrag f;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const f32x2 x = {v[8 * S + j], v[8 * S + j + 1]};
-        const f16x2 h = __builtin_convertvector(x, f16x2);
-        const f32x2 r = x - __builtin_convertvector(h, f32x2);
-        const f16x2 l = __builtin_convertvector(r, f16x2);
-        f.hi[j] = h.x; f.hi[j + 1] = h.y;
-        f.lo[j] = l.x; f.lo[j + 1] = l.y;
-    }
-    return f;
-}
-
 DEV f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
 // One fp32 product as TERMS fp16 products accumulated in fp32, smallest first:
@@ -226,6 +210,18 @@ DEV void mfma_f16(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
 template <int N>
 DEV void gelu_pairs(f32x2 (&x)[N]);
 
+// lo = f16(x - f32(hi)) for a pair, in two instructions: v_fma_mix{lo,hi}_f16 read the fp16 half of
+// `hi` directly, form hi * -1 + x in fp32 (exact: hi is x rounded to 11 bits) and write the rounded
+// fp16 result into one half of the destination.  Same bits as convert / subtract / convert (checked
+// on 2^21 values), three instructions per pair for the whole split instead of five.
+DEV f16x2 split_lo_pair(f16x2 hi, f32x2 x) {
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hb), "v"(x.x));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hb), "v"(x.y));
+    return __builtin_bit_cast(f16x2, lo);
+}
+
 // hi/lo fp16 split of register pair P (0..3) of k-step KS into elements 2P, 2P+1 of a fragment.
 // GELU_IN: the tile holds pre-activations and GELU is applied here, on the way into the
 // contraction - the activation of k-step ks+1 then sits between the MFMAs of k-step ks of the
@@ -241,8 +237,7 @@ DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
         x = t[0];
     }
     const f16x2 hh = __builtin_convertvector(x, f16x2);
-    const f32x2 rem = x - __builtin_convertvector(hh, f32x2);
-    const f16x2 ll = __builtin_convertvector(rem, f16x2);
+    const f16x2 ll = split_lo_pair(hh, x);
     f.hi[2 * p] = hh.x; f.hi[2 * p + 1] = hh.y;
     f.lo[2 * p] = ll.x; f.lo[2 * p + 1] = ll.y;
 }
