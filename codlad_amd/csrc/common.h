@@ -151,7 +151,7 @@ DEV void gemm128(Tile &acc, const Tile &in, const float *__restrict__ Wpacked, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32-equivalent contraction on the fp16 matrix pipe ("f16x4").
+// fp32-equivalent contraction on the fp16 matrix pipe ("f16x4" / "f16x3").
 //
 // v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 vector lanes: measured on MI355X
 // (tools/ubench/coexec.hip) a wave issuing fp32 MFMAs and a partner wave issuing v_fma_f32 take
@@ -201,12 +201,13 @@ DEV void mfma_f16(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
     }
 }
 
-// acc += W(128x128, f16x4-packed block in LDS) @ in.  128 f16 MFMAs in 32 groups (k-step, out
-// block) of four; weight fragments are read from LDS two groups ahead through a register ring.
+// acc += W(128x128, split-fp16 packed block in LDS) @ in: 32 groups (k-step, out block) of TERMS f16
+// MFMAs; weight fragments are read from LDS two groups ahead through a register ring.
 //
-// Measured on MI355X (tools/ubench/fill.hip, coexec.hip): fp32 VALU work placed between f16 MFMAs
-// is mostly NOT hidden (75-85 % of its stand-alone time is exposed, in the same wave or in the
-// SIMD partner), only transcendentals are; so the goal is simply the fewest VALU instructions.
+// Measured on MI355X (tools/ubench/coexec2.hip, phases.hip, phases2.hip): about six fp32 VALU
+// instructions ride free under one f16 MFMA, the rest of the vector work adds to the matrix time,
+// whether it is interleaved in the same wave, run as a separate phase or issued by the SIMD
+// partner; so the goal is simply the fewest VALU instructions.
 template <int N>
 DEV void gelu_pairs(f32x2 (&x)[N]);
 

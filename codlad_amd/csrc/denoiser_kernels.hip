@@ -92,10 +92,9 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Split-fp16 edge kernels (precision 1 = f16x4, 2 = f16x3).  Persistent 512-thread workgroups, one per CU: the two (three)
 // 64 KB weight blocks of the MLP live in LDS for the whole launch - 128 KB for the message kernel,
-// 160 KB for the edge update (W11e, W12 and the first four k-steps of W13; its last four k-steps
-// stream from L2) - and every wave walks nodes with a grid stride.  The contraction runs on the
-// f16 matrix pipe while the fp32 lanes do the split / bias / GELU / reduction work of the other
-// wave on the SIMD.
+// 152 KB for the edge update (W12, W13 and the first three k-steps of W11e; its last five k-steps
+// stream from L2, see below) - and every wave walks its nodes with a stride (wave_node_span).  The
+// contraction runs on the f16 matrix pipe, split / bias / GELU / reduction on the fp32 lanes.
 // ---------------------------------------------------------------------------------------------
 #define LDS_BLOCK_U4 4096   // one 64 KB packed block in 16-byte words
 
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
 }
 
 // Message kernel, split-fp16 contractions: S[n] = sum_j GELU(W2 GELU(P_i + Q_j + W1e h_E[i,j]) + b2) over the K
-// neighbours.  Same LDS residency as edge_kernel_h; on top of that
+// neighbours.  Same LDS residency scheme as upd_kernel_h; on top of that
 //   * the LAST contraction is issued with swapped MFMA operands, so its output block arrives
 //     transposed (lane = feature, registers = the tile's 32 edges): the sum over neighbours is
 //     then 15 register adds per block instead of a 5-step cross-lane reduction per register;
@@ -962,7 +961,7 @@ struct Layer0Args {
     const int2 *snode_info;
     const float *hE0;
     const float *W_msg, *W_upd;      // fp32-packed
-    const void *Wh_msg, *Wh_upd;     // f16x4-packed
+    const void *Wh_msg, *Wh_upd;     // split-fp16 packed
     float *E1;                       // [2][n_snodes][64][128]
     int n_snodes;
 };

@@ -41,7 +41,7 @@ def pack_block(w, scale=1.0):
 
 
 def _pack_index_h():
-    """(row, col) of the source block for every element of the f16x4 order
+    """(row, col) of the source block for every element of the split-fp16 (f16x3 / f16x4) order
     [k-step][out block][split][lane][8 halves] (split handled by the caller)."""
     ks, bo, lane, j = np.meshgrid(np.arange(8), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
     b, s_, h = ks >> 1, ks & 1, lane >> 5
@@ -131,7 +131,7 @@ def denoiser_tensors(sd):
 
 
 def denoiser_tensors_h(sd):
-    """f16x4 copies of every 128x128 block, same names with an `h.` prefix."""
+    """Split-fp16 (hi/lo) copies of every 128x128 block, same names with an `h.` prefix."""
     sd = strip_module_prefix(sd)
     g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
     t = OrderedDict()

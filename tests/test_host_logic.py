@@ -64,7 +64,7 @@ def test_pack_block_matches_library_packer():
     assert np.array_equal(np.sort(dst), np.sort(2.0 * blk.numpy().reshape(-1)))
 
 
-def test_f16x4_block_packing():
+def test_split_f16_block_packing():
     """hi + lo fp16 halves reproduce the fp32 weight to <= 2^-22 relative (or the fp16 subnormal
     spacing), in the [k-step][out block][split][lane][8] order the kernels read."""
     from codlad_amd.weights import pack_block_h
