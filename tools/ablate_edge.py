@@ -28,6 +28,12 @@ VARIANTS = {
     "base": ([], []),
     "nogelu": ([], [("common.h", "    if (GELU_IN) {\n        f32x2 t[1] = {x};", "    if (false) {\n        f32x2 t[1] = {x};"),
                     ("denoiser_kernels.hip", "        tile_gelu(t2);\n", "")]),
+    # node kernel (timed through the whole job: tools/ablate_edge.py bench <variants>)
+    "node_nofetch": ([], [("denoiser_kernels.hip", "        if (more) fetch(cur + 1);\n", ""),
+                          ("denoiser_kernels.hip", "        if (more) commit(cur + 1);\n", "")]),
+    "node_nobarrier": ([], [("denoiser_kernels.hip", "        if (more) commit(cur + 1);\n        __syncthreads();\n", "        if (more) commit(cur + 1);\n")]),
+    "node_nomfma": ([], [("denoiser_kernels.hip", "        if (gelu_in) gemm128_h_lds<TERMS, true>(acc, in, w, lane);\n        else gemm128_h_lds<TERMS, false>(acc, in, w, lane);\n        if (more) commit(cur + 1);",
+                           "        acc.b[0][0] += in.b[1][1] + __builtin_bit_cast(float, w[lane][0]);\n        if (more) commit(cur + 1);")]),
     "noglb": ([], [("denoiser_kernels.hip",
                     "                tail1.run(acc, x, lane);                                    // layer 1, streamed k-steps\n", "")]),
     "noln": ([], [("denoiser_kernels.hip", "            tile_layernorm_affine(x, 1e-6f, c_modA, c_modB, h);\n", "")]),
@@ -90,3 +96,11 @@ if __name__ == "__main__":
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "run1", n])
     elif mode == "run1":
         run_one(names[0])
+    elif mode == "bench":     # whole-job rate per variant (for kernels the launch hook does not cover)
+        for n in names:
+            env = dict(os.environ, CODLAD_HIP_LIB=os.path.join(OUT, f"libcodlad_{n}.so"))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                                  "--no-cpu-baseline"], env=env, capture_output=True, text=True).stdout
+            import json
+            d = json.loads(out.strip().splitlines()[-1])
+            print(f"{n:16s} {d['value']:.1f} structures/s   {d['ms_per_step']:.1f} ms per job", flush=True)
