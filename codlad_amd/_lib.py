@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 3   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -44,7 +44,7 @@ class DenoiserWeights(C.Structure):
                [(n, P) for n in ("x_in_w", "x_in_b", "pos_w", "pos_b", "edge_wT", "norm_w", "norm_b",
                                  "We_wT", "We_b", "out_w", "out_b")] + \
                [("enc", EncLayer * 3), ("dec", DecLayer * 3), ("precision", C.c_int),
-                ("enc_h", EncLayerH * 3), ("dec_h", DecLayerH * 3)]
+                ("enc_h", EncLayerH * 3), ("dec_h", DecLayerH * 3), ("self_condition", C.c_int)]
 
 
 class Workspace(C.Structure):
@@ -80,10 +80,10 @@ _SIGS = {
     "codlad_features_prepass": (C.c_int, [C.POINTER(DenoiserWeights), P, P, C.c_int, C.c_int, P, P, P]),
     "codlad_step_mods": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P]),
     "codlad_layer0_edge_terms": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P]),
-    "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P,
+    "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P,
                                           C.POINTER(Workspace), P]),
-    "codlad_ddpm_update": (C.c_int, [P, P, P, P, C.c_int, P, P]),
-    "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P,
+    "codlad_ddpm_update": (C.c_int, [P, P, P, P, C.c_int, P, P, P]),
+    "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P, P,
                                      C.c_int, C.POINTER(Workspace), P]),
     "codlad_vq_lookup": (C.c_int, [P, C.c_int, P, P, P, C.c_int, P, P, P, P]),
     "codlad_ic_decode": (C.c_int, [C.POINTER(DecoderWeights), P, P, P, P, P, C.c_int, P, P, P]),

@@ -526,12 +526,14 @@ DEV void tile_modulate(Tile &t, const float *shift, const float *scale, const fl
 
 // One reverse-diffusion update of a scalar (gaussian_diffusion.py:313-318, 364-367, 246-249, 446),
 // every product and sum rounded separately like the reference's elementwise tensor ops.
-DEV float ddpm_step(float xt, float eps, float v, const float *cf, float noise) {
+// *x0_out (optional) receives pred_xstart, the self-conditioning input of the next step.
+DEV float ddpm_step(float xt, float eps, float v, const float *cf, float noise, float *x0_out = nullptr) {
 #pragma clang fp contract(off)
     const float frac = (v + 1.0f) / 2.0f;
     const float logvar = frac * cf[5] + (1.0f - frac) * cf[4];
     const float x0 = cf[0] * xt - cf[1] * eps;
     const float mean = cf[2] * x0 + cf[3] * xt;
+    if (x0_out) *x0_out = x0;
     return mean + (cf[6] * expf(0.5f * logvar)) * noise;
 }
 

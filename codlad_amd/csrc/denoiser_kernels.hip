@@ -366,6 +366,8 @@ struct NodeArgs {
     const int4 *node_info;
     int n_nodes;
     const float *x, *x_in_w, *x_in_b;  // MODE_IN
+    const float *x_sc;                 // MODE_IN with self-conditioning: previous pred_xstart (null = zeros)
+    int in_dim;                        // 3, or 6 = [x_self_cond | x] (latent_model.py:210-212)
     const float *S;                    // MODE_UPD
     float *hV;
     const float *W3, *b3;
@@ -397,14 +399,23 @@ __global__ __launch_bounds__(64, 1) void node_kernel(NodeArgs a) {
     Tile v;
     if (!MODE_UPD) {
         const float x0 = a.x[nc * 3 + 0], x1 = a.x[nc * 3 + 1], x2 = a.x[nc * 3 + 2];
+        const bool sc = a.in_dim == 6;
+        const bool have_sc = sc && a.x_sc != nullptr;
+        const float s0 = have_sc ? a.x_sc[nc * 3 + 0] : 0.f, s1 = have_sc ? a.x_sc[nc * 3 + 1] : 0.f,
+                    s2 = have_sc ? a.x_sc[nc * 3 + 2] : 0.f;
         tile_load_row(v, a.x_in_b, h);
 #pragma unroll
         for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float *wr = a.x_in_w + f * 3;
-                v.b[bo][r] += fmaf(x2, wr[2], fmaf(x1, wr[1], x0 * wr[0]));
+                const float *wr = a.x_in_w + f * a.in_dim;
+                float acc = 0.f;
+                if (sc) {   // input = cat(x_self_cond, x): weight columns 0-2 | 3-5
+                    acc = fmaf(s2, wr[2], fmaf(s1, wr[1], s0 * wr[0]));
+                    wr += 3;
+                }
+                v.b[bo][r] += fmaf(x2, wr[2], fmaf(x1, wr[1], fmaf(x0, wr[0], acc)));
             }
     } else {
         Tile s, t;
@@ -527,14 +538,23 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
     Tile v;
     if (!MODE_UPD) {
         const float x0 = a.x[nc * 3 + 0], x1 = a.x[nc * 3 + 1], x2 = a.x[nc * 3 + 2];
+        const bool sc = a.in_dim == 6;
+        const bool have_sc = sc && a.x_sc != nullptr;
+        const float s0 = have_sc ? a.x_sc[nc * 3 + 0] : 0.f, s1 = have_sc ? a.x_sc[nc * 3 + 1] : 0.f,
+                    s2 = have_sc ? a.x_sc[nc * 3 + 2] : 0.f;
         tile_load_row(v, a.x_in_b, h);
 #pragma unroll
         for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float *wr = a.x_in_w + f * 3;
-                v.b[bo][r] += fmaf(x2, wr[2], fmaf(x1, wr[1], x0 * wr[0]));
+                const float *wr = a.x_in_w + f * a.in_dim;
+                float acc = 0.f;
+                if (sc) {   // input = cat(x_self_cond, x): weight columns 0-2 | 3-5
+                    acc = fmaf(s2, wr[2], fmaf(s1, wr[1], s0 * wr[0]));
+                    wr += 3;
+                }
+                v.b[bo][r] += fmaf(x2, wr[2], fmaf(x1, wr[1], fmaf(x0, wr[0], acc)));
             }
     } else {
         Tile s, t;
@@ -604,6 +624,7 @@ struct FinalArgs {
     float *x;           // in/out [n][3] (update mode)
     const float *noise; // [n][3]
     const float *coef;  // device [8]
+    float *x_start;     // [n][3] or null: pred_xstart of this step (self-conditioning input of the next)
 };
 
 __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
@@ -648,7 +669,7 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
         a.x[(size_t)n * 3 + k] = ddpm_step(a.x[(size_t)n * 3 + k], o[k], o[3 + k], a.coef,
-                                           a.noise[(size_t)n * 3 + k]);
+                                           a.noise[(size_t)n * 3 + k], a.x_start ? a.x_start + (size_t)n * 3 + k : nullptr);
 }
 
 // stand-alone DDPM update on a model output [n][6]
@@ -657,11 +678,11 @@ struct DdpmCoef {
 };
 
 __global__ void ddpm_kernel(const float *x, const float *out, const float *noise, DdpmCoef cf,
-                            int n_nodes, float *x_out) {
+                            int n_nodes, float *x_out, float *x_start) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes * 3) return;
     const int n = i / 3, k = i - 3 * n;
-    x_out[i] = ddpm_step(x[i], out[n * 6 + k], out[n * 6 + 3 + k], cf.c, noise[i]);
+    x_out[i] = ddpm_step(x[i], out[n * 6 + k], out[n * 6 + 3 + k], cf.c, noise[i], x_start ? x_start + i : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -795,7 +816,7 @@ static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t
 // One denoiser forward up to (not including) the final layer: leaves h_V in ws->hV.
 static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                             int n_nodes, const int32_t *E_idx, const float *h_E0, const float *E1,
-                            size_t n_snodes, const float *x, const float *mods_t,
+                            size_t n_snodes, const float *x, const float *x_self_cond, const float *mods_t,
                             const codlad_workspace *ws, hipStream_t st) {
     const int4 *ni = reinterpret_cast<const int4 *>(node_info);
     const size_t NS = (size_t)n_nodes * HD;
@@ -806,6 +827,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         NodeArgs na = {};
         na.node_info = ni; na.n_nodes = n_nodes;
         na.x = x; na.x_in_w = w->x_in_w; na.x_in_b = w->x_in_b; na.hV = ws->hV;
+        na.x_sc = x_self_cond; na.in_dim = w->self_condition ? 6 : 3;
         na.n_proj = 2;
         na.proj_w[0] = w->enc[0].W1a; na.proj_b[0] = w->enc[0].b1; na.proj_out[0] = PQ0;
         na.proj_w[1] = w->enc[0].W1c; na.proj_b[1] = nullptr;      na.proj_out[1] = PQ1;
@@ -907,13 +929,14 @@ extern "C" int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t 
 extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                                        int n_nodes, const int32_t *E_idx, const float *h_E0,
                                        const float *E1, int n_snodes, const float *x,
-                                       const float *mods_t, float *out, const codlad_workspace *ws,
-                                       void *stream) {
+                                       const float *x_self_cond, const float *mods_t, float *out,
+                                       const codlad_workspace *ws, void *stream) {
     CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && x && mods_t && out, "null pointer");
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
     CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
     hipStream_t st = (hipStream_t)stream;
-    enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, mods_t, ws, st);
+    CODLAD_REQUIRE(!x_self_cond || w->self_condition, "x_self_cond given to a model without self-conditioning");
+    enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, x_self_cond, mods_t, ws, st);
     FinalArgs fa = {};
     fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
     fa.n_nodes = n_nodes; fa.logits = out;
@@ -922,33 +945,39 @@ extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const i
 }
 
 extern "C" int codlad_ddpm_update(const float *x, const float *model_out, const float *noise,
-                                  const float *coef_host, int n_nodes, float *x_out, void *stream) {
+                                  const float *coef_host, int n_nodes, float *x_out, float *x_start_out,
+                                  void *stream) {
     CODLAD_REQUIRE(x && model_out && noise && coef_host && x_out, "null pointer");
     CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
     DdpmCoef cf;
     for (int k = 0; k < 8; ++k) cf.c[k] = coef_host[k];
     hipLaunchKernelGGL(ddpm_kernel, dim3((n_nodes * 3 + 255) / 256), dim3(256), 0,
-                       (hipStream_t)stream, x, model_out, noise, cf, n_nodes, x_out);
+                       (hipStream_t)stream, x, model_out, noise, cf, n_nodes, x_out, x_start_out);
     return codlad_check_launch("codlad_ddpm_update");
 }
 
 extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_t *node_info,
                                   int n_nodes, const int32_t *E_idx, const float *h_E0,
-                                  const float *E1, int n_snodes, float *x, const float *noise,
-                                  const float *mods, const float *coef, int T,
+                                  const float *E1, int n_snodes, float *x, float *x_start,
+                                  const float *noise, const float *mods, const float *coef, int T,
                                   const codlad_workspace *ws, void *stream) {
     CODLAD_REQUIRE(w && node_info && E_idx && h_E0 && x && noise && mods && coef, "null pointer");
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
     CODLAD_REQUIRE(n_nodes > 0 && T > 0, "n_nodes and T must be positive");
+    CODLAD_REQUIRE(!w->self_condition || x_start, "a self-conditioned model needs the x_start buffer");
     hipStream_t st = (hipStream_t)stream;
+    // self-conditioning (gaussian_diffusion.py:530-547): step k reads the pred_xstart step k-1 wrote;
+    // the first step gets none, which the model treats as zeros (latent_model.py:211)
+    const bool sc = w->self_condition != 0;
     for (int k = 0; k < T; ++k) {
         const int i = T - 1 - k;
         const float *mods_t = mods + (size_t)i * CODLAD_MODS_PER_STEP;
-        enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, mods_t, ws, st);
+        enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, sc && k > 0 ? x_start : nullptr,
+                        mods_t, ws, st);
         FinalArgs fa = {};
         fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
         fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
-        fa.coef = coef + (size_t)i * 8;
+        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start;
         hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
     }
     return codlad_check_launch("codlad_sample_loop");

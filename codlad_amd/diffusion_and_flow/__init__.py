@@ -37,13 +37,12 @@ class SpacedDiffusion(Tables):
         if model_mean_type is not ModelMeanType.EPSILON or model_var_type is not ModelVarType.LEARNED_RANGE:
             raise NotImplementedError("only epsilon prediction with LEARNED_RANGE variance is built "
                                       "(the configuration test.py samples with)")
-        if self_condition:
-            raise NotImplementedError("self-conditioning is not on the mpnn_diffusion sampling path")
         super().__init__(betas, set(use_timesteps))
         self.use_timesteps = set(use_timesteps)
         self.original_num_steps = len(betas)
         self.model_mean_type, self.model_var_type = model_mean_type, model_var_type
-        self.loss_type, self.self_condition = loss_type, False
+        # reference gaussian_diffusion.py:172, 530-547: each step is conditioned on the previous pred_xstart
+        self.loss_type, self.self_condition = loss_type, bool(self_condition)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -88,6 +87,9 @@ class SpacedDiffusion(Tables):
         n_rep = img.shape[0] // int(batch["num_CGs"].shape[0])
         job, lens = mod.job_for(batch, n_rep)
         mod._check_mask(model_kwargs.get("mask"), lens, n_rep)
+        if self.self_condition != mod.self_condition:
+            raise ValueError("create_diffusion(self_condition=...) and the model's self_condition differ: the fused "
+                             "loop conditions exactly when the model was built for it (test.py:297-303)")
         if len(set(lens)) != 1:
             raise NotImplementedError("fused loop on a padded mixed-length batch; pass equal-length "
                                       "structures per call (what the reference's loaders produce)")
@@ -102,12 +104,15 @@ class SpacedDiffusion(Tables):
         self._check_args(clip_denoised, denoised_fn, cond_fn)
         model_kwargs = model_kwargs or {}
         img = noise if noise is not None else torch.randn(*shape, device=device)
+        x_start = None
         for k, i in enumerate(range(self.num_timesteps - 1, -1, -1)):
             t = torch.tensor([i] * shape[0], device=img.device)
             eps = step_noise[k] if step_noise is not None else torch.randn_like(img)
-            out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, noise=eps)
+            out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, noise=eps,
+                                x_self_cond=x_start if self.self_condition else None)
             yield out
             img = out["sample"]
+            x_start = out["pred_xstart"]
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  x_self_cond=None, noise=None):
@@ -117,7 +122,10 @@ class SpacedDiffusion(Tables):
         from .. import _lib
         i = int(t.reshape(-1)[0])
         map_t = torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)[t]   # respace.py:124-129
-        model_out = model(x, map_t, **(model_kwargs or {}))
+        kwargs = dict(model_kwargs or {})
+        if x_self_cond is not None:
+            kwargs["x_self_cond"] = x_self_cond
+        model_out = model(x, map_t, **kwargs)
         if noise is None:
             noise = torch.randn_like(x)
         C = x.shape[-1]
@@ -127,12 +135,13 @@ class SpacedDiffusion(Tables):
         coef = np.ascontiguousarray(self.step_coefficients()[i])
         xs = x.contiguous().float()
         out = torch.empty_like(xs)
+        x_start = torch.empty_like(xs)
         rc = _lib.lib().codlad_ddpm_update(_lib.ptr(xs), _lib.ptr(model_out.contiguous().float()),
                                            _lib.ptr(noise.contiguous().float()),
                                            coef.ctypes.data_as(ctypes.c_void_p), xs.numel() // 3,
-                                           _lib.ptr(out), _lib.stream_ptr(x.device))
+                                           _lib.ptr(out), _lib.ptr(x_start), _lib.stream_ptr(x.device))
         _lib.check(rc, "codlad_ddpm_update")
-        return {"sample": out, "pred_xstart": None}
+        return {"sample": out, "pred_xstart": x_start}
 
 
 def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, rescale_learned_sigmas=False,

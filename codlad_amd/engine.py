@@ -137,18 +137,30 @@ class Denoiser:
         return self._mods_cache[key]
 
     # -- per call ------------------------------------------------------------------------------
-    def forward(self, job, x, t_value):
-        """One denoiser call: x [n_nodes,3] -> [n_nodes,6] (eps | variance logits)."""
+    @property
+    def self_condition(self):
+        return self.weights.self_condition
+
+    def forward(self, job, x, t_value, x_self_cond=None):
+        """One denoiser call: x [n_nodes,3] -> [n_nodes,6] (eps | variance logits).  x_self_cond
+        [n_nodes,3]: previous pred_xstart, for a self-conditioned model only (None = zeros)."""
         _require_cuda(x, "x")
         x = x.contiguous().float()
         assert x.shape == (job.n_nodes, 3)
+        if x_self_cond is not None:
+            if not self.self_condition:
+                raise ValueError("x_self_cond given to a model built without self_condition")
+            _require_cuda(x_self_cond, "x_self_cond")
+            x_self_cond = x_self_cond.contiguous().float()
+            assert x_self_cond.shape == x.shape
         mods = self.step_mods([t_value])
         out = torch.empty(job.n_nodes, 6, dtype=torch.float32, device=self.device)
         st = job.structures
         rc = self.lib.codlad_denoiser_forward(C.byref(self.weights.struct), _lib.ptr(job.node_info),
                                               job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
-                                              _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(mods),
-                                              _lib.ptr(out), C.byref(job.ws), _lib.stream_ptr(self.device))
+                                              _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(x_self_cond),
+                                              _lib.ptr(mods), _lib.ptr(out), C.byref(job.ws),
+                                              _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_denoiser_forward")
         return out
 
@@ -164,26 +176,28 @@ class Denoiser:
         mods = self.step_mods(tables.timestep_map)
         coef = torch.from_numpy(tables.step_coefficients()).to(self.device)
         st = job.structures
+        x_start = torch.empty_like(x) if self.self_condition else None   # pred_xstart, step to step
         rc = self.lib.codlad_sample_loop(C.byref(self.weights.struct), _lib.ptr(job.node_info),
                                          job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
-                                         _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(noise),
-                                         _lib.ptr(mods), _lib.ptr(coef), T, C.byref(job.ws),
+                                         _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(x_start),
+                                         _lib.ptr(noise), _lib.ptr(mods), _lib.ptr(coef), T, C.byref(job.ws),
                                          _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_sample_loop")
         return x
 
-    def ddpm_update(self, x, model_out, noise, tables, i):
+    def ddpm_update(self, x, model_out, noise, tables, i, return_x_start=False):
         _require_cuda(x, "x")
         n = x.numel() // 3
         x = x.contiguous().float()
         out = torch.empty_like(x)
+        x_start = torch.empty_like(x) if return_x_start else None
         coef = np.ascontiguousarray(tables.step_coefficients()[i])
         rc = self.lib.codlad_ddpm_update(_lib.ptr(x), _lib.ptr(model_out.contiguous().float()),
                                          _lib.ptr(noise.contiguous().float()),
-                                         coef.ctypes.data_as(C.c_void_p), n, _lib.ptr(out),
+                                         coef.ctypes.data_as(C.c_void_p), n, _lib.ptr(out), _lib.ptr(x_start),
                                          _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_ddpm_update")
-        return out
+        return (out, x_start) if return_x_start else out
 
 
 class Decoder:

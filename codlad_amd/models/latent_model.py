@@ -95,8 +95,8 @@ class ProteinMPNN_diffusion_new(nn.Module):
             unsupported.append("k_neighbors != 64 / vocab != 30 / full-backbone features")
         if augment_eps != 0.0 or decoder_mask or not use_seq_in_encoder or use_input_decoding_order:
             unsupported.append("anything but the `mpnn_diffusion` configuration")
-        if self_condition or not final_adln or diffusion != "diffusion" or input_size != 3:
-            unsupported.append("self-conditioning / plain output head / non-DDPM heads / latent_size != 3")
+        if not final_adln or diffusion != "diffusion" or input_size != 3:
+            unsupported.append("plain output head / non-DDPM heads / latent_size != 3")
         if unsupported:
             raise NotImplementedError("the HIP path builds the reference's mpnn_diffusion model only; "
                                       "not supported: " + "; ".join(unsupported))
@@ -104,7 +104,8 @@ class ProteinMPNN_diffusion_new(nn.Module):
         self.decoder_mask, self.use_seq_in_encoder, self.final_adln = decoder_mask, use_seq_in_encoder, final_adln
         self.hidden_dim = hidden_dim
         self.t_embedder = _TimestepParams(hidden_dim)
-        self.x_in = nn.Linear(input_size, hidden_dim)
+        # self-conditioning doubles the input: x_in sees cat(x_self_cond, x) (reference latent_model.py:112-116)
+        self.x_in = nn.Linear(2 * input_size if self_condition else input_size, hidden_dim)
         self.features = _FeatureParams(edge_features)
         self.W_e = nn.Linear(edge_features, hidden_dim, bias=True)
         self.W_s = nn.Embedding(vocab, hidden_dim)
@@ -169,8 +170,8 @@ class ProteinMPNN_diffusion_new(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("ProteinMPNN_diffusion_new (codlad_amd) runs on the MI355X only; "
                                "move the model and inputs to cuda")
-        if x_self_cond is not None:
-            raise NotImplementedError("self-conditioning is not part of the mpnn_diffusion path")
+        if x_self_cond is not None and not self.self_condition:
+            raise ValueError("x_self_cond given to a model built with self_condition=False")
         B = int(batch["num_CGs"].shape[0])
         N = int(x.shape[0])
         if N % B:
@@ -183,11 +184,13 @@ class ProteinMPNN_diffusion_new(nn.Module):
         if tt.numel() > 1 and not bool((tt == t0).all()):
             raise NotImplementedError("per-sample timesteps: the sampler uses one timestep per call")
         L = x.shape[1]
-        if len(set(lens)) == 1:
-            flat = x.reshape(-1, x.shape[-1])
-        else:  # padded mixed-length batch -> ragged
-            flat = torch.cat([x[s, :n] for s, n in enumerate(lens * n_rep)], dim=0)
-        out = self.engine().forward(job, flat, t0)
+        def ragged(v):
+            if len(set(lens)) == 1:
+                return v.reshape(-1, v.shape[-1])
+            return torch.cat([v[s, :n] for s, n in enumerate(lens * n_rep)], dim=0)   # padded mixed-length batch
+
+        flat = ragged(x)
+        out = self.engine().forward(job, flat, t0, None if x_self_cond is None else ragged(x_self_cond))
         if len(set(lens)) == 1:
             return out.view(N, L, -1)
         res = out.new_zeros(N, L, out.shape[-1])

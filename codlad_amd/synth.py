@@ -69,7 +69,7 @@ def _linear(rng, sd, name, out_f, in_f, bias=True, gain=1.0, bias_std=0.1):
         sd[f"{name}.bias"] = _t(rng.standard_normal((out_f,)) * bias_std)
 
 
-def denoiser_state_dict(seed=1234, input_size=3):
+def denoiser_state_dict(seed=1234, input_size=3, self_condition=False):
     """Non-degenerate weights with the key layout of the reference's
     `ProteinMPNN_diffusion_new` (108 tensors; reference models/latent_model.py:119-148).
 
@@ -82,7 +82,8 @@ def denoiser_state_dict(seed=1234, input_size=3):
     sd = OrderedDict()
     _linear(rng, sd, "t_embedder.mlp.0", H, 256)
     _linear(rng, sd, "t_embedder.mlp.2", H, H)
-    _linear(rng, sd, "x_in", H, input_size, gain=1.0)
+    # self_condition: x_in sees cat(x_self_cond, x) (reference latent_model.py:112-116)
+    _linear(rng, sd, "x_in", H, 2 * input_size if self_condition else input_size, gain=1.0)
     _linear(rng, sd, "features.embeddings.linear", 16, 66)
     _linear(rng, sd, "features.edge_embedding", H, 167, bias=False, gain=2.0)
     sd["features.norm_edges.weight"] = _t(1.0 + 0.1 * rng.standard_normal(H))

@@ -86,7 +86,8 @@ def denoiser_tensors(sd):
         t[f"ada_w{i}"] = g(f"{hname}.adaLN_modulation.1.weight")
         t[f"ada_b{i}"] = g(f"{hname}.adaLN_modulation.1.bias")
     t["x_in_w"], t["x_in_b"] = g("x_in.weight"), g("x_in.bias")
-    assert t["x_in_w"].shape == (H, 3), "only latent_size 3 (N6/K3/K4) is built"
+    # [128,3], or [128,6] for a self_condition model: columns = cat(x_self_cond, x) (latent_model.py:112-116, 210-212)
+    assert t["x_in_w"].shape in ((H, 3), (H, 6)), "only latent_size 3 (N6/K3/K4) is built"
     t["pos_w"], t["pos_b"] = g("features.embeddings.linear.weight"), g("features.embeddings.linear.bias")
     t["edge_wT"] = g("features.edge_embedding.weight").t().contiguous()
     t["norm_w"], t["norm_b"] = g("features.norm_edges.weight"), g("features.norm_edges.bias")
@@ -234,6 +235,7 @@ class DenoiserWeights:
         tensors.update(denoiser_tensors_h(state_dict))
         self.blob = Blob(tensors, device)
         self.precision = precision
+        self.self_condition = tensors["x_in_w"].shape[1] == 6
         self.struct = self._fill()
 
     def _fill(self):
@@ -263,6 +265,7 @@ class DenoiserWeights:
                 eh.Win[c], eh.Wout[c] = p(f"h.enc{l}.Win{c}"), p(f"h.enc{l}.Wout{c}")
                 dh.Win[c], dh.Wout[c] = p(f"h.dec{l}.Win{c}"), p(f"h.dec{l}.Wout{c}")
         w.precision = PRECISIONS[self.precision]
+        w.self_condition = int(self.self_condition)
         return w
 
     def set_precision(self, precision):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 2
+#define CODLAD_ABI_VERSION 3
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -91,7 +91,7 @@ typedef struct {
     const float *t_w0, *t_b0;          /* t_embedder.mlp.0  [128][256], [128]                  */
     const float *t_w2, *t_b2;          /* t_embedder.mlp.2  [128][128], [128]                  */
     const float *ada_w[7], *ada_b[7];  /* adaLN heads: enc0..2 [1152][128], dec0..2 [768][128], final [256][128] */
-    const float *x_in_w, *x_in_b;      /* [128][3], [128]                                      */
+    const float *x_in_w, *x_in_b;      /* [128][3] ([128][6] with self_condition), [128]       */
     const float *pos_w, *pos_b;        /* features.embeddings.linear [16][66], [16]            */
     const float *edge_wT;              /* features.edge_embedding.weight TRANSPOSED [167][128] */
     const float *norm_w, *norm_b;      /* features.norm_edges                                   */
@@ -108,6 +108,10 @@ typedef struct {
     int precision;
     codlad_enc_layer_h enc_h[3];
     codlad_dec_layer_h dec_h[3];
+    /* 1: the model was built with self_condition=True (latent_model.py:112-116): x_in takes
+     * cat(x_self_cond, x) and the sampler feeds each step the previous step's pred_xstart
+     * (gaussian_diffusion.py:530-547). */
+    int self_condition;
 } codlad_denoiser_weights;
 
 /* Row 4: CA_ProteinFeatures.forward + W_e
@@ -145,26 +149,29 @@ int codlad_layer0_edge_terms(const codlad_denoiser_weights *w, const int32_t *sn
 
 /* Rows 5-7: one denoiser forward (latent_model.py:175-268): x [n_nodes][3] -> out [n_nodes][6].
  * mods_t = the 6016 modulation floats of this timestep.  E1 (may be NULL) from
- * codlad_layer0_edge_terms, n_snodes = its structure-node count. */
+ * codlad_layer0_edge_terms, n_snodes = its structure-node count.  x_self_cond [n_nodes][3]: only for
+ * a self_condition model, NULL = zeros (latent_model.py:211). */
 int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                             int n_nodes, const int32_t *E_idx, const float *h_E0,
-                            const float *E1, int n_snodes, const float *x, const float *mods_t,
-                            float *out, const codlad_workspace *ws, void *stream);
+                            const float *E1, int n_snodes, const float *x, const float *x_self_cond,
+                            const float *mods_t, float *out, const codlad_workspace *ws, void *stream);
 
 /* Row 2: one reverse step given the model output (gaussian_diffusion.py:404-449, 262-360).
  * coef_host[8] = {sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2,
  *                 post_log_var_clipped, log_beta, nonzero(0/1), 0} for this step. */
 int codlad_ddpm_update(const float *x, const float *model_out, const float *noise,
-                       const float *coef_host, int n_nodes, float *x_out, void *stream);
+                       const float *coef_host, int n_nodes, float *x_out, float *x_start_out /* pred_xstart, may be NULL */,
+                       void *stream);
 
 /* Rows 2-7 fused: p_sample_loop (gaussian_diffusion.py:451-547, respace.py:124-129).
  * x [n_nodes][3] holds x_T on entry and x_0 on return.  noise [T][n_nodes][3] is consumed in
  * loop order (entry 0 at step T-1).  mods [T][6016] and coef [T][8] (device) are indexed by
- * respaced step i; the loop runs i = T-1 .. 0. */
+ * respaced step i; the loop runs i = T-1 .. 0.  x_start [n_nodes][3] (may be NULL unless the model
+ * is self-conditioned) receives every step's pred_xstart and is what the next step is conditioned on. */
 int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_t *node_info, int n_nodes,
                        const int32_t *E_idx, const float *h_E0, const float *E1, int n_snodes,
-                       float *x, const float *noise, const float *mods, const float *coef, int T,
-                       const codlad_workspace *ws, void *stream);
+                       float *x, float *x_start, const float *noise, const float *mods, const float *coef,
+                       int T, const codlad_workspace *ws, void *stream);
 
 /* Row 8: get_norm_feature(norm_in=False) + nearest code
  * (utils/dataset_module.py:253; utils/vq_module.py:61-68 / VectorQuantize eval lookup).

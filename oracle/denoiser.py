@@ -186,7 +186,7 @@ def final_layer(sd, h_V, c):
     return _lin(sd, "W_out.linear", _mod(_ln(h_V), shift, scale))
 
 
-def forward(sd, x, t, cg_xyz, cg_z, mask, features=None, taps=None):
+def forward(sd, x, t, cg_xyz, cg_z, mask, features=None, taps=None, x_self_cond=None):
     """latent_model.py:175-268 for `mpnn_diffusion` (decoder_mask=False, use_seq_in_encoder=True).
 
     x [N,L,3]; t [N] (already mapped through timestep_map); cg_xyz [N,L,3]; cg_z [N,L] int64;
@@ -196,6 +196,8 @@ def forward(sd, x, t, cg_xyz, cg_z, mask, features=None, taps=None):
     c = t_embed(sd, t)
     maski = mask.int()
     E, E_idx = ca_features(sd, cg_xyz, maski) if features is None else features
+    if sd["x_in.weight"].shape[1] == 2 * x.shape[-1]:     # self_condition model, latent_model.py:210-212
+        x = torch.cat((torch.zeros_like(x) if x_self_cond is None else x_self_cond, x), dim=-1)
     h_V = _lin(sd, "x_in", x)
     h_E = _lin(sd, "W_e", E)
     if taps is not None:

@@ -15,7 +15,7 @@ def _coef(arr, i):
     return torch.from_numpy(arr)[i].float()
 
 
-def ddpm_update(sched, i, x, model_out, noise):
+def ddpm_update(sched, i, x, model_out, noise, return_x_start=False):
     """One reverse step given the denoiser output [N,L,6]; returns x_{i-1}."""
     C = x.shape[-1]
     eps, v = torch.split(model_out, C, dim=-1)
@@ -27,11 +27,12 @@ def ddpm_update(sched, i, x, model_out, noise):
         - _coef(sched["sqrt_recipm1_alphas_cumprod"], i) * eps
     mean = _coef(sched["posterior_mean_coef1"], i) * x0 + _coef(sched["posterior_mean_coef2"], i) * x
     nonzero = 0.0 if i == 0 else 1.0
-    return mean + nonzero * torch.exp(0.5 * log_var) * noise
+    sample = mean + nonzero * torch.exp(0.5 * log_var) * noise
+    return (sample, x0) if return_x_start else sample
 
 
 def p_sample_loop(sd, num_steps, z, noise, cg_xyz, cg_z, mask, hoist_features=False,
-                  return_traj=False):
+                  return_traj=False, self_condition=False):
     """z [N,L,3] = x_T; noise [T,N,L,3] consumed in loop order (first entry at i = T-1).
 
     hoist_features=False recomputes the CA features every step like the reference does;
@@ -41,10 +42,12 @@ def p_sample_loop(sd, num_steps, z, noise, cg_xyz, cg_z, mask, hoist_features=Fa
     feats = denoiser.ca_features(sd, cg_xyz, mask.int()) if hoist_features else None
     x = z
     traj = []
+    x_start = None       # gaussian_diffusion.py:530-547: each step sees the previous pred_xstart
     for k, i in enumerate(range(T - 1, -1, -1)):
         t = torch.full((x.shape[0],), int(sched["timestep_map"][i]), dtype=torch.int64)
-        out = denoiser.forward(sd, x, t, cg_xyz, cg_z, mask, features=feats)
-        x = ddpm_update(sched, i, x, out, noise[k])
+        out = denoiser.forward(sd, x, t, cg_xyz, cg_z, mask, features=feats,
+                               x_self_cond=x_start if self_condition else None)
+        x, x_start = ddpm_update(sched, i, x, out, noise[k], return_x_start=True)
         if return_traj:
             traj.append(x)
     return (x, traj) if return_traj else x

@@ -39,7 +39,7 @@ def build_model(args):
 def load_denoiser(args, device):
     model = build_model(args)
     if args.synthetic_weights:
-        model.load_state_dict(synth.denoiser_state_dict(1234), strict=True)
+        model.load_state_dict(synth.denoiser_state_dict(1234, self_condition=args.self_condition), strict=True)
     else:
         tag = {"best": "best", "last": "last"}.get(args.model_step, f"step_{args.model_step}")
         ckpt = torch.load(f"./results/{args.exp}/protein_weights_{tag}.pt", map_location="cpu")
@@ -103,7 +103,9 @@ def main(args):
         model = load_denoiser(args, device)
         diffusion = create_diffusion(str(args.num_sampling_steps), noise_schedule=args.noise_schedule,
                                      predict_xstart=args.predict_xstart,
-                                     rescale_learned_sigmas=args.rescale_learned_sigmas, self_condition=False)
+                                     rescale_learned_sigmas=args.rescale_learned_sigmas,
+                                     # reference test.py:297-303
+                                     self_condition=hasattr(model, "self_condition") and args.self_condition)
     elif args.experiment != "recon":
         raise NotImplementedError(f"experiment {args.experiment!r}: latent and recon are built")
     save_dir = f"./logs/generated_samples_{args.sample_index}_{args.model_step}/{args.exp}_{args.data_type}"

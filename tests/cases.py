@@ -30,6 +30,12 @@ LOOP_CASES = {
     "L87_B1_T100": (87, 1, 13, 100),
 }
 
+SELF_COND_CASES = {
+    # name -> (n_cg, n_frames, seed, T): models built with self_condition=True (--self_condition)
+    "L46_B2_T10": (46, 2, 61, 10),
+    "L87_B1_T10": (87, 1, 62, 10),
+}
+
 DECODER_CASES = {
     # name -> (n_cg, n_frames, seed, vae_type)
     "N6_L46_B3": (46, 3, 31, "N6"),

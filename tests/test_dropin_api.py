@@ -49,7 +49,9 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         ProteinMPNN_diffusion_new(input_size=36, diffusion="diffusion")       # default ctor = not mpnn_diffusion
     with pytest.raises(NotImplementedError):
-        MPNN_models["mpnn_diffusion"](input_size=3, diffusion="diffusion", self_condition=True)
+        MPNN_models["mpnn_diffusion"](input_size=3, diffusion="flow")
+    sc = MPNN_models["mpnn_diffusion"](input_size=3, diffusion="diffusion", self_condition=True)
+    assert sc.self_condition and tuple(sc.x_in.weight.shape) == (128, 6)        # latent_model.py:112-116
     with pytest.raises(NotImplementedError):
         create_diffusion("100", predict_xstart=True)
     with pytest.raises(NotImplementedError):

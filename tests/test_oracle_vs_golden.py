@@ -179,3 +179,21 @@ def test_g8_metrics(name):
                loss_inter=inter, loss_pi_pi=pipi)
     for k, v in got.items():
         assert float(v) == pytest.approx(float(gold[k]), rel=1e-6, abs=1e-9), k
+
+
+@pytest.mark.parametrize("name", list(cases.SELF_COND_CASES))
+def test_g9_self_conditioning(name):
+    """--self_condition: x_in over cat(x_self_cond, x) and the pred_xstart feedback of the sampler
+    (latent_model.py:210-212, gaussian_diffusion.py:530-547)."""
+    L, B, seed, T = cases.SELF_COND_CASES[name]
+    gold = g(f"g9_selfcond_{name}")
+    sd_sc = synth.denoiser_state_dict(cases.WEIGHT_SEED, self_condition=True)
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, m = denoiser.batch_to_dense(batch)
+    xsc = synth.gaussian((B, L, 3), 6000 + seed)
+    assert rel_err(denoiser.forward(sd_sc, x, t, cg_xyz, cg_z, m), gold["out_none"]) < 1e-5
+    assert rel_err(denoiser.forward(sd_sc, x, t, cg_xyz, cg_z, m, x_self_cond=xsc), gold["out_sc"]) < 1e-5
+    z, eps = cases.loop_noise(T, B, L, seed)
+    xs, traj = sampler.p_sample_loop(sd_sc, T, z, eps, cg_xyz, cg_z, m, return_traj=True, self_condition=True)
+    assert rel_err(torch.stack(traj), gold["traj"]) < 2e-5
+    assert rel_err(xs, gold["sample"]) < 2e-5

@@ -77,6 +77,26 @@ def save(name, **arrays):
 
 
 # ----------------------------------------------------------------------------
+def g9_self_condition(ref):
+    """Next row 8f-4: the --self_condition variant (reference test.py:196, 297-303): a model built with
+    self_condition=True (x_in sees cat(x_self_cond, x), latent_model.py:112-116, 210-212) and a sampler
+    that feeds each step the previous pred_xstart (gaussian_diffusion.py:530-547)."""
+    print("g9 self-conditioning")
+    model = ref["MPNN_models"]["mpnn_diffusion"](input_size=3, unconditional=True, diffusion="diffusion",
+                                                 self_condition=True)
+    model.load_state_dict(synth.denoiser_state_dict(cases.WEIGHT_SEED, self_condition=True), strict=True)
+    model.eval()
+    for name, (L, B, seed, T) in cases.SELF_COND_CASES.items():
+        prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+        xsc = synth.gaussian((B, L, 3), 6000 + seed)
+        out_none = model(x, t, None, mask=mask, batch=batch)                       # x_self_cond -> zeros
+        out_sc = model(x, t, None, mask=mask, batch=batch, x_self_cond=xsc)
+        z, eps = cases.loop_noise(T, B, L, seed)
+        traj = run_loop(ref, model, T, z, eps, mask, batch, self_condition=True)
+        save(f"g9_selfcond_{name}", out_none=out_none, out_sc=out_sc, sample=traj[-1], traj=torch.stack(traj))
+
+
+# ----------------------------------------------------------------------------
 def g8_metrics(ref):
     """The evaluation helpers that follow the path in the reference's loop (test.py:97-166, called at
     :589-593), run on the synthetic lists of tests/cases.py."""
@@ -183,10 +203,10 @@ class NoiseFeeder:
         return e
 
 
-def run_loop(ref, model, T, z, eps, mask, batch):
+def run_loop(ref, model, T, z, eps, mask, batch, self_condition=False):
     import diffusion_and_flow.gaussian_diffusion as gd
     d = ref["create_diffusion"](str(T), noise_schedule="linear", predict_xstart=False,
-                                rescale_learned_sigmas=False, self_condition=False)
+                                rescale_learned_sigmas=False, self_condition=self_condition)
     feeder = NoiseFeeder(eps)
     orig = gd.th.randn_like
     gd.th.randn_like = feeder
@@ -358,6 +378,7 @@ def main():
     if want("g6"): g6_ic_to_xyz(ref)
     if want("g7"): g7_end_to_end(ref, model)
     if want("g8"): g8_metrics(ref)
+    if want("g9"): g9_self_condition(ref)
 
 
 if __name__ == "__main__":
