@@ -335,36 +335,45 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
 
 // GELU(x) = x Phi(x) = max(x, 0) - |x| * (erfc(|x|/sqrt 2) / 2), branch-free:
 //   s = min(|x|, 4 sqrt 2),   erfc(s/sqrt 2)/2 = exp2(s g(s) - 1),
-// g a degree-8 minimax fit of log2(erfc t)/t on t in [0,4] re-expressed in s (so neither the
-// 1/sqrt 2 nor the 1/2 costs an instruction; one v_exp_f32 finishes it).  13 VALU instructions
-// (min, 8 fma, fma, exp, max, fma with |.| and - as source modifiers) against ~45 plus divergent
-// branches for the library erff; max absolute error 2.5e-7 over [-8, 8] (fp32 evaluation of the
-// textbook formula with a correctly rounded erf: 2.4e-7), and x * (tiny) keeps full relative
-// accuracy in the negative tail.  -DCODLAD_EXACT_ERF selects erff() for A/B validation.
-#define CODLAD_GELU_C0 5.136640197633824e-07f
-#define CODLAD_GELU_C1 -9.57114389166236e-06f
-#define CODLAD_GELU_C2 7.503479719161987e-05f
-#define CODLAD_GELU_C3 -0.00028452760307118297f
-#define CODLAD_GELU_C4 1.5291185263777152e-05f
-#define CODLAD_GELU_C5 0.006930838339030743f
-#define CODLAD_GELU_C6 -0.05243462696671486f
-#define CODLAD_GELU_C7 -0.4592214822769165f
-#define CODLAD_GELU_C8 -1.1511043310165405f
+// g a polynomial fit of log2(erfc(s/sqrt 2))/s on [0, 4 sqrt 2] (so neither the 1/sqrt 2 nor the 1/2
+// costs an instruction; one v_exp_f32 finishes it).  The fit minimises the error of GELU itself,
+// |x| (erfc/2) ln2 s |dg|: where erfc is tiny, g may be far off, and that is what lets a low degree
+// reach fp32 level.  Degree CODLAD_GELU_DEGREE = 5 (default; 6 and 8 selectable for A/B runs):
+//   max |error| over |x| < 1 / 2 / 4 / 8:   deg 5  1.4e-7 / 1.6e-7 / 2.2e-7 / 3.1e-7
+//                                           deg 6  0.9e-7 / 1.2e-7 / 1.6e-7 / 2.8e-7
+//                                           deg 8  0.6e-7 / 0.9e-7 / 1.4e-7 / 2.4e-7
+//   x/2 (1 + erf(x/sqrt 2)) in fp32 with a correctly rounded erf (what the reference computes):
+//                                                  0.9e-7 / 1.6e-7 / 3.0e-7 / 4.5e-7
+// (beyond |x| ~ 2 every variant is at the rounding of its own fp32 output).  x * (tiny) keeps full
+// relative accuracy in the negative tail.  10 VALU instructions at degree 5 (min, 6 fma, exp, max,
+// fma with |.| and - as source modifiers) against ~45 plus divergent branches for the library erff.
+// -DCODLAD_EXACT_ERF selects erff() for A/B validation.
+#ifndef CODLAD_GELU_DEGREE
+#define CODLAD_GELU_DEGREE 5
+#endif
 #define CODLAD_GELU_CLAMP 5.656854249492381f
+#if CODLAD_GELU_DEGREE == 5
+#define CODLAD_GELU_COEFFS {2.992418740177527e-05f, -0.0007398742018267512f, 0.007977462373673916f, \
+                            -0.05323818698525429f, -0.45891568064689636f, -1.1511471271514893f}
+#elif CODLAD_GELU_DEGREE == 6
+#define CODLAD_GELU_COEFFS {4.27874283559504e-06f, -1.2798205716535449e-05f, -0.0005757861654274166f, \
+                            0.0076707834377884865f, -0.052948564291000366f, -0.4590439200401306f, -1.1511269807815552f}
+#elif CODLAD_GELU_DEGREE == 8
+#define CODLAD_GELU_COEFFS {5.136640197633824e-07f, -9.57114389166236e-06f, 7.503479719161987e-05f,          \
+                            -0.00028452760307118297f, 1.5291185263777152e-05f, 0.006930838339030743f,       \
+                            -0.05243462696671486f, -0.4592214822769165f, -1.1511043310165405f}
+#else
+#error "CODLAD_GELU_DEGREE must be 5, 6 or 8"
+#endif
 DEV float gelu_erf(float x) {
 #ifdef CODLAD_EXACT_ERF
     return (0.5f * x) * (1.0f + erff(x * 0.70710678118654752440f));
 #else
+    constexpr float cf[CODLAD_GELU_DEGREE + 1] = CODLAD_GELU_COEFFS;
     const float s = fminf(fabsf(x), CODLAD_GELU_CLAMP);
-    float p = CODLAD_GELU_C0;
-    p = fmaf(p, s, CODLAD_GELU_C1);
-    p = fmaf(p, s, CODLAD_GELU_C2);
-    p = fmaf(p, s, CODLAD_GELU_C3);
-    p = fmaf(p, s, CODLAD_GELU_C4);
-    p = fmaf(p, s, CODLAD_GELU_C5);
-    p = fmaf(p, s, CODLAD_GELU_C6);
-    p = fmaf(p, s, CODLAD_GELU_C7);
-    p = fmaf(p, s, CODLAD_GELU_C8);
+    float p = cf[0];
+#pragma unroll
+    for (int k = 1; k <= CODLAD_GELU_DEGREE; ++k) p = fmaf(p, s, cf[k]);
     const float e = __builtin_amdgcn_exp2f(fmaf(p, s, -1.0f));
     return fmaf(-e, fabsf(x), fmaxf(x, 0.0f));
 #endif
@@ -394,6 +403,7 @@ DEV float half_wave_sum(float v) {
 // v_pk_fma_f32 that consumes the previous one's result otherwise costs an s_nop).
 template <int N>
 DEV void gelu_pairs(f32x2 (&x)[N]) {
+    constexpr float cf[CODLAD_GELU_DEGREE + 1] = CODLAD_GELU_COEFFS;
     f32x2 t[N], p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -401,18 +411,13 @@ DEV void gelu_pairs(f32x2 (&x)[N]) {
         t[i].y = fminf(fabsf(x[i].y), CODLAD_GELU_CLAMP);
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = t[i] * CODLAD_GELU_C0 + CODLAD_GELU_C1;
-#define CODLAD_HORNER(c)                     \
-    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + (c);
-    CODLAD_HORNER(CODLAD_GELU_C2)
-    CODLAD_HORNER(CODLAD_GELU_C3)
-    CODLAD_HORNER(CODLAD_GELU_C4)
-    CODLAD_HORNER(CODLAD_GELU_C5)
-    CODLAD_HORNER(CODLAD_GELU_C6)
-    CODLAD_HORNER(CODLAD_GELU_C7)
-    CODLAD_HORNER(CODLAD_GELU_C8)
-    CODLAD_HORNER(-1.0f)
-#undef CODLAD_HORNER
+    for (int i = 0; i < N; ++i) p[i] = t[i] * cf[0] + cf[1];
+#pragma unroll
+    for (int k = 2; k <= CODLAD_GELU_DEGREE; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + cf[k];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + -1.0f;     // s g(s) - 1
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float ex = __builtin_amdgcn_exp2f(p[i].x), ey = __builtin_amdgcn_exp2f(p[i].y);
