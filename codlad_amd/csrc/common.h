@@ -45,6 +45,14 @@ DEV void tile_load_row(Tile &t, const float *row, int h) {
         }
 }
 
+// pair (r, r+1) of an accumulator block as a packed fp32 operand / result (adjacent, even-aligned
+// registers: v_pk_add / v_pk_mul / v_pk_fma work on them in place, two elements per issue slot)
+DEV f32x2 tile_pair(const f32x16 &v, int r) { return f32x2{v[r], v[r + 1]}; }
+DEV void tile_set_pair(f32x16 &v, int r, f32x2 x) {
+    v[r] = x.x;
+    v[r + 1] = x.y;
+}
+
 DEV void tile_add_row(Tile &t, const float *row, int h) {
     const float4 *p = reinterpret_cast<const float4 *>(row);
 #pragma unroll
@@ -52,10 +60,8 @@ DEV void tile_add_row(Tile &t, const float *row, int h) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 v = p[8 * bo + 2 * q + h];
-            t.b[bo][4 * q + 0] += v.x;
-            t.b[bo][4 * q + 1] += v.y;
-            t.b[bo][4 * q + 2] += v.z;
-            t.b[bo][4 * q + 3] += v.w;
+            tile_set_pair(t.b[bo], 4 * q, tile_pair(t.b[bo], 4 * q) + f32x2{v.x, v.y});
+            tile_set_pair(t.b[bo], 4 * q + 2, tile_pair(t.b[bo], 4 * q + 2) + f32x2{v.z, v.w});
         }
 }
 
@@ -485,17 +491,26 @@ DEV void tile_layernorm(Tile &t, float eps) {
 // A = gate (1 + scale), B = gate shift (two vectors instead of three, two VALU per element
 // instead of four; the moments are computed exactly as in tile_layernorm).
 DEV void tile_layernorm_affine(Tile &t, float eps, const float *A, const float *B, int h) {
-    const float mean = column_sum128(tile_own_sum(t)) * (1.0f / 128.0f);
-    float v = 0.f;
+    // packed fp32 throughout (pairs of adjacent accumulator registers): the sums run over two
+    // interleaved partial sums, which is also what halves their dependency chains
+    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = t.b[bo][r] - mean;
-            t.b[bo][r] = d;
-            v += d * d;
+        for (int r = 0; r < 16; r += 2) s2 += tile_pair(t.b[bo], r);
+    const float mean = column_sum128(s2.x + s2.y) * (1.0f / 128.0f);
+    const f32x2 m2 = {mean, mean};
+    f32x2 v2 = {0.f, 0.f};
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 d = tile_pair(t.b[bo], r) - m2;
+            tile_set_pair(t.b[bo], r, d);
+            v2 = d * d + v2;
         }
-    const float rstd = 1.0f / sqrtf(column_sum128(v) * (1.0f / 128.0f) + eps);
+    const float rstd = 1.0f / sqrtf(column_sum128(v2.x + v2.y) * (1.0f / 128.0f) + eps);
+    const f32x2 r2 = {rstd, rstd};
     const float4 *pa = reinterpret_cast<const float4 *>(A);
     const float4 *pb = reinterpret_cast<const float4 *>(B);
 #pragma unroll
@@ -504,10 +519,8 @@ DEV void tile_layernorm_affine(Tile &t, float eps, const float *A, const float *
         for (int q = 0; q < 4; ++q) {
             const int o = 8 * bo + 2 * q + h;
             const float4 ka = pa[o], kb = pb[o];
-            t.b[bo][4 * q + 0] = fmaf(t.b[bo][4 * q + 0], rstd * ka.x, kb.x);
-            t.b[bo][4 * q + 1] = fmaf(t.b[bo][4 * q + 1], rstd * ka.y, kb.y);
-            t.b[bo][4 * q + 2] = fmaf(t.b[bo][4 * q + 2], rstd * ka.z, kb.z);
-            t.b[bo][4 * q + 3] = fmaf(t.b[bo][4 * q + 3], rstd * ka.w, kb.w);
+            tile_set_pair(t.b[bo], 4 * q, tile_pair(t.b[bo], 4 * q) * (r2 * f32x2{ka.x, ka.y}) + f32x2{kb.x, kb.y});
+            tile_set_pair(t.b[bo], 4 * q + 2, tile_pair(t.b[bo], 4 * q + 2) * (r2 * f32x2{ka.z, ka.w}) + f32x2{kb.z, kb.w});
         }
 }
 
