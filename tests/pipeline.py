@@ -35,8 +35,16 @@ class Config:
         r = torch.randn(self.T + 1, L, 3, generator=g, device=self.device)
         return r[0], r[1:]
 
-    def run_units(self, unit_ids):
-        """-> {unit id: (x0 [L,3], idx [L], xyz [n_atoms,3])} (device tensors)."""
+    def unit_latent(self, u):
+        """cfg 5 (--experiment recon): a normalised latent per unit in place of the e3nn encoder's."""
+        L = self.lengths[self.units[u][0]]
+        g = torch.Generator(device=self.device)
+        g.manual_seed(77 + u)
+        return torch.randn(L, 3, generator=g, device=self.device)
+
+    def run_units(self, unit_ids, decode_only=False):
+        """-> {unit id: (x0 [L,3], idx [L], xyz [n_atoms,3])} (device tensors).  decode_only: skip the
+        sampler and decode `unit_latent` (VQ + IC decoder + ic_to_xyz only)."""
         unit_ids = sorted(unit_ids)
         # the structures this job needs, each once
         s_key = sorted({self.units[u][:2] for u in unit_ids})
@@ -48,10 +56,13 @@ class Config:
             z_list.append(torch.from_numpy(prot["z_full"])[1:-1])
         st = self.den.prepare_structures(xyz_list, z_list)
         job = self.den.make_job(st, [s_of[self.units[u][:2]] for u in unit_ids])
-        noise = [self.unit_noise(u) for u in unit_ids]
-        x_T = torch.cat([n[0] for n in noise])
-        eps = torch.cat([n[1] for n in noise], dim=1)
-        x0 = self.den.sample(job, x_T, eps, self.tables)
+        if decode_only:
+            x0 = torch.cat([self.unit_latent(u) for u in unit_ids])
+        else:
+            noise = [self.unit_noise(u) for u in unit_ids]
+            x_T = torch.cat([n[0] for n in noise])
+            eps = torch.cat([n[1] for n in noise], dim=1)
+            x0 = self.den.sample(job, x_T, eps, self.tables)
         idx, zq, _lat = self.dec.vq(x0)
         ni = job.node_info
         cg_z = ni[:, 3].contiguous()

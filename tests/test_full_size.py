@@ -73,6 +73,35 @@ def test_cfg2_ped_n6_full_size():
     assert not torch.equal(whole[0][0], whole[1][0])
 
 
+def test_cfg5_recon_decoder_only_full_size():
+    """cfg 5 (--experiment recon): cfg-2 geometry, VQ + IC decoder + ic_to_xyz only, on latents that stand in
+    for the (out-of-scope) e3nn encoder's; replay, sharding invariance, and two units against the CPU oracle."""
+    from oracle import vae_decode as odec
+    cfg = pipeline.Config("cfg5", PED_LENGTHS, n_frames=10, n_ensemble=10, vae_type="N6", dataname="PED")
+    units = list(range(400))
+    whole = cfg.run_units(units, decode_only=True)
+    again = cfg.run_units(units, decode_only=True)
+    shards = parallel.shard_units([parallel.unit_cost(cfg.lengths[cfg.units[u][0]]) for u in units], 2)
+    part = cfg.run_units([units[i] for i in shards[1]], decode_only=True)
+    for u in units:
+        assert pipeline.same(whole[u], again[u]), u
+    for i in shards[1]:
+        assert pipeline.same(whole[units[i]], part[units[i]]), i
+    vsd = synth.vqvae_state_dict("N6", "PED", pipeline.VAE_SEED)
+    mean, std = synth.norm_stats("PED", "N6")
+    for u in (0, 399):
+        p, f, _m = cfg.units[u]
+        prot = cfg.proteins[p]
+        L = prot["n_cg"]
+        batch = synth.make_batch(prot, frame_ids=[f])
+        lat = odec.denormalise(cfg.unit_latent(u).cpu()[None], mean, std)
+        idx, ic = odec.latent_decode(vsd, lat, batch)
+        xyz = odec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4), ic.reshape(-1, L, 13, 3), prot["info"])
+        assert torch.equal(whole[u][1].cpu(), idx.reshape(-1))                      # code indices bit-exact
+        rmsd = float(((whole[u][2].cpu() - xyz[0]) ** 2).sum(-1).mean().sqrt())
+        assert rmsd < 1e-4, (u, rmsd)
+
+
 def test_cfg3_pdb_k3_full_size():
     """cfg 3: 64 proteins, one frame each, lengths 50-400, angle decoder (K3); all 64 on one GPU and
     two of the eight per-GPU shards."""
