@@ -165,3 +165,40 @@ def test_graft_entry_build_runs_on_cpu():
     dlopen, resolve every symbol, check the ABI version, import the oracle."""
     import __graft_entry__
     __graft_entry__.build()
+
+
+def test_shard_units_properties():
+    """LPT sharding (codlad_amd/parallel.py) for arbitrary unit mixes: every unit exactly once, shards
+    sorted, deterministic, and the classic LPT bound: max load <= mean load + the largest unit."""
+    from hypothesis import given, settings, strategies as st
+    from codlad_amd import parallel
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=505), min_size=0, max_size=300),
+           st.integers(min_value=1, max_value=8))
+    def check(lengths, world):
+        costs = [parallel.unit_cost(L) for L in lengths]
+        shards = parallel.shard_units(costs, world)
+        assert len(shards) == world
+        assert sorted(u for s in shards for u in s) == list(range(len(costs)))
+        assert all(s == sorted(s) for s in shards)
+        assert shards == parallel.shard_units(costs, world)
+        if costs:
+            loads = [sum(costs[u] for u in s) for s in shards]
+            assert max(loads) <= sum(costs) / world + max(costs)
+
+    check()
+
+
+def test_edge_block_layout_helper():
+    """engine.edge_rows undoes the chunk-major edge-block layout documented in include/codlad_hip.h
+    (feature f of edge e at 256*(f/4) + 4*e + f%4)."""
+    from codlad_amd.engine import edge_rows
+    n = 3
+    rows = torch.arange(n * 64 * 128, dtype=torch.float32).view(n, 64, 128)
+    blocks = torch.empty(n, 32, 64, 4)
+    for f in range(128):
+        blocks[:, f // 4, :, f % 4] = rows[:, :, f]
+    assert torch.equal(edge_rows(blocks), rows)
+    flat = blocks.view(n, -1)
+    assert float(flat[1, 256 * (77 // 4) + 4 * 13 + 77 % 4]) == float(rows[1, 13, 77])
