@@ -165,9 +165,9 @@ DEV void gemm128(Tile &acc, const Tile &in, const float *__restrict__ Wpacked, i
 // fp32 contraction.  The f16 MFMA (32x32x16, 32 cycles for 16 k) has its own pipe and 16x the rate.
 // Both operands are split into two fp16 halves by round-to-nearest,
 //     x = hi + lo (+ eps),  hi = f16(x),  lo = f16(x - hi),  |eps| <= 2^-22 |x|
-// and all four partial products hi*hi + hi*lo + lo*hi + lo*lo are accumulated in fp32 by the MFMA
-// (fp16 x fp16 products are exact in fp32).  Per 16 k this costs 4 x 32 = 128 matrix-pipe cycles
-// against 8 x 64 = 512 ALU cycles for the fp32 MFMA, and the ALUs stay free for the epilogues.
+// and the partial products hi*hi + hi*lo + lo*hi (+ lo*lo in the four-term mode, see mfma_f16) are
+// accumulated in fp32 by the MFMA (fp16 x fp16 products are exact in fp32).  Per 16 k this costs
+// 3-4 x 32 = 96-128 matrix-pipe cycles against 8 x 64 = 512 ALU cycles for the fp32 MFMA.
 //
 // Layout: same chain as above.  k-step ks = 2*b + s consumes registers 8s..8s+7 of input block b;
 // element j of lane half h is feature 32*b + 16*s + 8*(j>>2) + 4*h + (j&3).  A packed weight block
@@ -250,7 +250,7 @@ DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
 }
 
 // One group = (k-step ks, out block bo): fragment prefetch for two groups ahead, a quarter of
-// the NEXT k-step's operand split (and GELU), four MFMAs.  The sched_barrier closes the
+// the NEXT k-step's operand split (and GELU), TERMS MFMAs.  The sched_barrier closes the
 // scheduling region: inside it the compiler interleaves the VALU instructions with the four
 // MFMAs; across it nothing moves, which keeps register pressure bounded (left alone, hipcc hoists
 // loads and epilogue arithmetic across the whole 128-MFMA block and spills hundreds of registers).
