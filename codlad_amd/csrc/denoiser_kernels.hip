@@ -325,10 +325,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
         if (cnt >= 32) {
 #pragma unroll
             for (int bo = 0; bo < 4; ++bo) {
-                float s0 = 0.f;
+                f32x2 s2 = tile_pair(t2.b[bo], 0);      // packed adds: two partial sums per block
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s0 += t2.b[bo][r];
-                sum[bo] += s0;
+                for (int r = 2; r < 16; r += 2) s2 += tile_pair(t2.b[bo], r);
+                sum[bo] += s2.x + s2.y;
             }
         } else {
 #pragma unroll
