@@ -86,12 +86,17 @@ def main(args):
     # ranks longest-first, every rank samples and decodes its own, rank 0 reports the totals
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    backend = os.environ.get("CODLAD_DIST_BACKEND", "nccl")   # "gloo": rehearsal of N > 1 on a one-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.set_grad_enabled(False)
     torch.manual_seed(args.seed + args.sample_index + 1000 * rank)
     np.random.seed(args.seed + args.sample_index)
@@ -150,7 +155,7 @@ def main(args):
               f"({B * E / dt:.1f} structures/s)", flush=True)
     if world > 1:
         import torch.distributed as dist
-        tot = torch.tensor([total], dtype=torch.int64, device=device)
+        tot = torch.tensor([total], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tot)
         total = int(tot)
         dist.destroy_process_group()
