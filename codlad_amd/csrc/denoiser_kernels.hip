@@ -495,32 +495,35 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
     const int4 info = a.node_info[nc];
     const int n_blk = (MODE_UPD ? 9 : 0) + a.n_proj;
 
-    u32x4 stage[PER_T];
     int cur = 0;                                          // index of the block resident in wl[(cur&1)]
-    auto fetch = [&](int i) {                             // global -> registers
+    // global -> LDS buffer (i & 1) without staging registers: global_load_lds_dwordx4 moves 16 bytes
+    // per lane, one wave instruction = 1 KB landing contiguously at the (wave-uniform) LDS address.
+    // The buffer being written is the one every wave left at the previous barrier.
+    auto fetch = [&](int i) {
         const u32x4 *g = reinterpret_cast<const u32x4 *>(a.blk_h[i]);
-#pragma unroll
-        for (int q = 0; q < PER_T; ++q) stage[q] = g[q * NT + tid];
-    };
-    auto commit = [&](int i) {                            // registers -> LDS buffer (i & 1)
         u32x4 *dst = wl + (i & 1) * LDS_BLOCK_U4;
 #pragma unroll
-        for (int q = 0; q < PER_T; ++q) dst[q * NT + tid] = stage[q];
+        for (int q = 0; q < PER_T; ++q) {
+            const int chunk = (q * NW + wave) * 64;
+            __builtin_amdgcn_global_load_lds(g + chunk + lane,
+                                             (__attribute__((address_space(3))) void *)(dst + chunk), 16, 0, 0);
+        }
     };
-    // contraction with the current block, then rotate the double buffer
+    auto landed = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };   // vmcnt(0): the LDS-direct loads are in
+    // contraction with the current block while the next one streams in, then rotate the double buffer
     auto apply = [&](Tile &acc, const Tile &in, bool gelu_in) {
         const bool more = cur + 1 < n_blk;
         if (more) fetch(cur + 1);
         const u32x4 *w = wl + (cur & 1) * LDS_BLOCK_U4;
         if (gelu_in) gemm128_h_lds<TERMS, true>(acc, in, w, lane);
         else gemm128_h_lds<TERMS, false>(acc, in, w, lane);
-        if (more) commit(cur + 1);
+        if (more) landed();
         __syncthreads();
         ++cur;
     };
     if (n_blk > 0) {
         fetch(0);
-        commit(0);
+        landed();
     }
     // both modulations folded to one multiply-add each (tile_layernorm_affine), kept in LDS behind
     // the double buffer: A = gate (1 + scale), B = gate shift
