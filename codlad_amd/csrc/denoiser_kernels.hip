@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 // the neighbour rows an edge tile gathers (neighbours are nodes of the same sample, i.e. of the
 // same chunk) and the edge state written by one edge kernel and read by the next then stay within
 // one XCD's L2 instead of being pulled into all eight.  Placement is a speed matter only.
-constexpr int NODE_WG_TILE = 128;                         // nodes per node-kernel workgroup (4 waves x 32)
+constexpr int NODE_WG_TILE = 256;                         // chunk granularity: the largest node-kernel workgroup (8 waves x 32)
 __host__ __device__ inline int xcd_chunk_nodes(int n_nodes) {
     const int wg_tiles = (n_nodes + NODE_WG_TILE - 1) / NODE_WG_TILE;
     return NODE_WG_TILE * ((wg_tiles + 7) / 8);
@@ -486,10 +486,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
     static_assert(LDS_BLOCK_U4 % NT == 0, "block must divide evenly over the workgroup");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
-    // workgroup -> 128-node tile: chunk (blockIdx % 8), see wave_node_span; the grid is 8 x tiles per chunk
-    const int wg_tile = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-    if (wg_tile * NODE_WG_TILE >= a.n_nodes) return;      // padding of the last chunk (whole workgroup)
-    const int node = (wg_tile * NW + wave) * 32 + c;
+    // workgroup -> its 32*NW nodes inside chunk (blockIdx % 8), see wave_node_span; grid = 8 x workgroups per chunk
+    const int wg_node0 = (blockIdx.x % 8) * xcd_chunk_nodes(a.n_nodes) + (blockIdx.x / 8) * (32 * NW);
+    if (wg_node0 >= a.n_nodes) return;                    // padding of the last chunk (whole workgroup)
+    const int node = wg_node0 + wave * 32 + c;
     const bool valid = node < a.n_nodes;
     const int nc = valid ? node : a.n_nodes - 1;
     const int4 info = a.node_info[nc];
@@ -790,9 +790,12 @@ static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStrea
     else hipLaunchKernelGGL(edge_kernel<false>, grid, block, 0, st, ea);
 }
 
-template <int TERMS>
-static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
-    constexpr int NW = 4;   // one 32-node tile per SIMD; eight waves (256 VGPRs each) spill ~150 registers
+// NW waves (32-node tiles) per workgroup, one workgroup per CU (LDS).  Four waves give every SIMD one
+// tile and the most workgroups; a job with more tiles than 4 x CUs would then need a second, mostly
+// empty round, and eight waves (two per SIMD, which overlap in this latency-bound kernel; a few
+// dozen spilled registers) finish in one and stream every weight block once per 256 nodes.
+template <int TERMS, int NW>
+static void launch_node_hw(bool upd, const NodeArgs &na, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = 2 * 65536 + 4 * 512;
     if (!attr_set) {
@@ -802,10 +805,16 @@ static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    static_assert(32 * NW == NODE_WG_TILE, "the XCD chunking assumes 128-node workgroup tiles");
-    dim3 grid(8 * (xcd_chunk_nodes(na.n_nodes) / NODE_WG_TILE)), block(NW * 64);
+    static_assert(NODE_WG_TILE % (32 * NW) == 0, "chunks hold whole workgroup tiles");
+    dim3 grid(8 * (xcd_chunk_nodes(na.n_nodes) / (32 * NW))), block(NW * 64);
     if (upd) hipLaunchKernelGGL((node_kernel_h<true, NW, TERMS>), grid, block, lds, st, na);
     else hipLaunchKernelGGL((node_kernel_h<false, NW, TERMS>), grid, block, lds, st, na);
+}
+
+template <int TERMS>
+static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
+    if ((na.n_nodes + 31) / 32 > 4 * num_cu()) launch_node_hw<TERMS, 8>(upd, na, st);
+    else launch_node_hw<TERMS, 4>(upd, na, st);
 }
 
 static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t st) {
