@@ -105,10 +105,16 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 // the neighbour rows an edge tile gathers (neighbours are nodes of the same sample, i.e. of the
 // same chunk) and the edge state written by one edge kernel and read by the next then stay within
 // one XCD's L2 instead of being pulled into all eight.  Placement is a speed matter only.
-constexpr int NODE_WG_TILE = 256;                         // chunk granularity: the largest node-kernel workgroup (8 waves x 32)
+// Chunk granularity: large jobs use 256 nodes (the largest node-kernel workgroup: 8 waves x 32), so
+// that the node kernel can follow the same chunks; below 32 768 nodes that would leave whole XCDs
+// without work (eight chunks of a multiple of 256 nodes), so chunks are cut to 32 nodes and the node
+// kernel keeps its plain order - at that size everything fits in any L2 anyway.
+constexpr int NODE_WG_TILE = 256;
+constexpr int XCD_CHUNKED_NODE_KERNEL_MIN = 32768;
 __host__ __device__ inline int xcd_chunk_nodes(int n_nodes) {
-    const int wg_tiles = (n_nodes + NODE_WG_TILE - 1) / NODE_WG_TILE;
-    return NODE_WG_TILE * ((wg_tiles + 7) / 8);
+    const int g = n_nodes >= XCD_CHUNKED_NODE_KERNEL_MIN ? NODE_WG_TILE : 32;
+    const int tiles = (n_nodes + g - 1) / g;
+    return g * ((tiles + 7) / 8);
 }
 
 struct NodeSpan {
@@ -486,8 +492,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
     static_assert(LDS_BLOCK_U4 % NT == 0, "block must divide evenly over the workgroup");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
-    // workgroup -> its 32*NW nodes inside chunk (blockIdx % 8), see wave_node_span; grid = 8 x workgroups per chunk
-    const int wg_node0 = (blockIdx.x % 8) * xcd_chunk_nodes(a.n_nodes) + (blockIdx.x / 8) * (32 * NW);
+    // large jobs: workgroup -> its 32*NW nodes inside chunk (blockIdx % 8), see wave_node_span (grid =
+    // 8 x workgroups per chunk); small jobs: plain order
+    const int wg_node0 = a.n_nodes >= XCD_CHUNKED_NODE_KERNEL_MIN
+                             ? (blockIdx.x % 8) * xcd_chunk_nodes(a.n_nodes) + (blockIdx.x / 8) * (32 * NW)
+                             : blockIdx.x * (32 * NW);
     if (wg_node0 >= a.n_nodes) return;                    // padding of the last chunk (whole workgroup)
     const int node = wg_node0 + wave * 32 + c;
     const bool valid = node < a.n_nodes;
@@ -806,7 +815,9 @@ static void launch_node_hw(bool upd, const NodeArgs &na, hipStream_t st) {
         attr_set = true;
     }
     static_assert(NODE_WG_TILE % (32 * NW) == 0, "chunks hold whole workgroup tiles");
-    dim3 grid(8 * (xcd_chunk_nodes(na.n_nodes) / (32 * NW))), block(NW * 64);
+    const int wgs = na.n_nodes >= XCD_CHUNKED_NODE_KERNEL_MIN ? 8 * (xcd_chunk_nodes(na.n_nodes) / (32 * NW))
+                                                              : (na.n_nodes + 32 * NW - 1) / (32 * NW);
+    dim3 grid(wgs), block(NW * 64);
     if (upd) hipLaunchKernelGGL((node_kernel_h<true, NW, TERMS>), grid, block, lds, st, na);
     else hipLaunchKernelGGL((node_kernel_h<false, NW, TERMS>), grid, block, lds, st, na);
 }
