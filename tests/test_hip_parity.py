@@ -411,3 +411,37 @@ def test_end_to_end(den, sd, name):
     if not bool(differ.any()):
         rmsd = float(((xyz.cpu() - torch.from_numpy(gold["xyz"])) ** 2).sum(-1).mean().sqrt())
         assert rmsd < 1e-4
+
+
+def test_random_ragged_jobs_against_oracle_and_between_modes(sd):
+    """Randomised shapes: tiny and odd lengths, repeated / unused structures, uneven ensemble sizes.
+    Each job: f16x3 against the f32-MFMA mode, two samples against the CPU oracle, and one sample
+    bit-for-bit against the same sample run alone."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    d3, d32 = Denoiser(sd, DEV, precision="f16x3"), Denoiser(sd, DEV, precision="f32")
+    for trial in range(6):
+        n_struct = int(rng.integers(2, 7))
+        lens = [int(x) for x in rng.choice([4, 5, 7, 16, 31, 32, 33, 40, 63, 64, 65, 97, 130, 201], n_struct)]
+        prots = [synth.make_protein(L, 500 + 10 * trial + i, n_frames=1) for i, L in enumerate(lens)]
+        xyz = [torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in prots]
+        zz = [torch.from_numpy(p["z_full"])[1:-1] for p in prots]
+        sample_struct = [int(s) for s in rng.integers(0, n_struct, int(rng.integers(1, 9)))]
+        n_nodes = sum(lens[s] for s in sample_struct)
+        x = synth.gaussian((n_nodes, 3), 900 + trial).to(DEV)
+        t = int(rng.integers(0, 1000))
+        outs = {}
+        for name, den in (("f16x3", d3), ("f32", d32)):
+            st = den.prepare_structures(xyz, zz)
+            outs[name] = den.forward(den.make_job(st, sample_struct), x, t)
+        assert bool(torch.isfinite(outs["f16x3"]).all())
+        assert rel_err(outs["f16x3"], outs["f32"]) < 5e-6, (trial, lens, sample_struct)
+        off = np.concatenate([[0], np.cumsum([lens[s] for s in sample_struct])])
+        for k in sorted({0, len(sample_struct) - 1}):
+            s = sample_struct[k]
+            a, b = int(off[k]), int(off[k + 1])
+            batch = synth.make_batch(prots[s])
+            cg_z, cg_xyz, m = oden.batch_to_dense(batch)
+            ref = oden.forward(sd, x[a:b].cpu()[None], torch.tensor([t]), cg_xyz, cg_z, m)
+            assert rel_err(outs["f16x3"][a:b], ref[0]) < 1e-5, (trial, k, lens[s])
+            alone = d3.forward(d3.make_job(d3.prepare_structures([xyz[s]], [zz[s]]), [0]), x[a:b], t)
+            assert torch.equal(alone, outs["f16x3"][a:b])
