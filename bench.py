@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the CODLAD sampling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg4share|cfg5]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): synthetic PED-shaped test set - 4 proteins with
+Default workload (BASELINE.json configs[1], "cfg2"): synthetic PED-shaped test set - 4 proteins with
 L = 46/87/92/129 residues, 10 frames each, num_ensemble = 10 -> 400 structures per GPU, 100-step
 respaced DDPM with the mpnn_diffusion denoiser, then de-normalise + VQ (4096 codes) + IC_Decoder
-(N6) + ic_to_xyz.  One "step" of this benchmark = that whole job, noise tensor resident in HBM
-to all-atom coordinates resident in HBM.  Ranks are independent replicas of the job on different
-seeds (weak scaling); weights are broadcast from rank 0 over RCCL before timing and every rank's
-coordinates are all-gathered inside the timed region.
+(N6) + ic_to_xyz.  One "step" of this benchmark = that whole job: CA traces and noise resident in HBM
+-> all-atom coordinates resident in HBM, INCLUDING the per-structure work (k-NN graph + edge features,
+hoisted layer-0 edge terms, the adaLN vectors of all timesteps, the decoder's CG graph).  For cfg2 / cfg5
+the ranks are independent replicas of the job on different seeds ("scaling": "weak"); cfg3 / cfg4 are ONE
+job whose units (protein, frame, ensemble member) are dealt to the ranks longest-first ("strong").  Weights
+are broadcast from rank 0 over RCCL before timing and every rank's coordinates are all-gathered inside the
+timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` times the dominant kernel (the per-edge message MLP,
-edge_kernel<false>) with HIP events on its own stream; `cpu_baseline` times the CPU oracle
-(oracle/, a port of the reference's PyTorch-CPU path) on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` times the dominant kernel (the per-edge message MLP) with HIP
+events on its own stream and prices it against the matrix pipe it runs on; `cpu_baseline` times the CPU
+oracle (oracle/, a port of the reference's PyTorch-CPU path) on a bounded sample of the same workload;
+`f32_mfma` is the same job with every contraction on v_mfma_f32_32x32x2_f32 (IEEE fp32 products).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -29,84 +34,138 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PED_LENGTHS = (46, 87, 92, 129)
-N_FRAMES = 10
-N_ENSEMBLE = 10
 T_STEPS = 100
 WEIGHT_SEED, VAE_SEED = 1234, 4321
-FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, matrix FP32
+# /opt/skills/guides/MI355X_MICROARCH.md: dense F16/BF16 MFMA ~2.5 PFLOP/s; fp32 matrix 157.3 TFLOP/s; HBM3E 8 TB/s
+F16_MFMA_PEAK_TFLOPS = 2500.0
+FP32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+DTYPE = {"f16x3": "f32 as f16x3 split (each fp32 operand = fp16 hi + fp16 lo, 22-bit; 3 f16 MFMAs per product, fp32 "
+                  "accumulate); everything outside the contractions fp32",
+         "f16x4": "f32 as f16x4 split (each fp32 operand = fp16 hi + fp16 lo, 22-bit; 4 f16 MFMAs per product, fp32 "
+                  "accumulate); everything outside the contractions fp32",
+         "f32": "f32 (v_mfma_f32_32x32x2_f32)"}
 
 
 def algorithmic_flop_per_structure(L):
     """per denoiser step per real sample 2*(786432*L*K + 787584*L + 819200),
-    K = min(64, L); features once per structure 2*37760*L*K."""
+    K = min(64, L); features once per structure 2*37760*L*K (computed inside the timed region)."""
     K = min(64, L)
     return T_STEPS * 2 * (786432 * L * K + 787584 * L + 819200) + 2 * 37760 * L * K
 
 
-class Workload:
-    """cfg 2 resident on one GPU."""
+def decode_bytes_per_structure(L, n_atoms, n_pairs):
+    """SURVEY.md §8(d), cfg 5: read latent 12 L + CA 16 (L+2) + pairs 16 E_undirected + tables 8 n_atoms +
+    240 L; write ic 156 L + xyz 12 n_atoms."""
+    return 12 * L + 16 * (L + 2) + 16 * n_pairs + 8 * n_atoms + 240 * L + 156 * L + 12 * n_atoms
 
-    def __init__(self, device, rank, precision="f16x3"):
-        from codlad_amd import synth
+
+class Workload:
+    """One rank's part of a BASELINE.json configuration, inputs resident on its GPU."""
+
+    def __init__(self, device, cfg_name, rank=0, world=1, precision="f16x3"):
+        from codlad_amd import parallel, synth
         from codlad_amd.engine import Decoder, Denoiser
         from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
-        self.device = device
-        self.precision = precision
+        cfg = synth.baseline_config(cfg_name)
+        self.cfg, self.cfg_name, self.device, self.precision = cfg, cfg_name, device, precision
+        self.decode_only = cfg["decode_only"]
+        strong = cfg["scaling"] == "strong"
         self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), device, precision=precision)
-        mean, std = synth.norm_stats("PED", "N6")
-        self.dec = Decoder(synth.vqvae_state_dict("N6", "PED", VAE_SEED), device, mean, std)
+        mean, std = synth.norm_stats(cfg["dataname"], cfg["vae_type"])
+        self.dec = Decoder(synth.vqvae_state_dict(cfg["vae_type"], cfg["dataname"], VAE_SEED), device, mean, std)
         self.tables = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T_STEPS)))
-        self.proteins = [synth.make_protein(L, 100 * rank + 1000 + i, n_frames=N_FRAMES)
-                         for i, L in enumerate(PED_LENGTHS)]
-        xyz_list, z_list, sample_struct, self.groups = [], [], [], []
-        for prot in self.proteins:
-            frames = torch.from_numpy(prot["xyz_full"])[:, 1:-1]
-            z = torch.from_numpy(prot["z_full"])[1:-1]
-            first = len(xyz_list)
-            for f in range(N_FRAMES):
-                xyz_list.append(frames[f])
-                z_list.append(z)
-            members = [first + f for f in range(N_FRAMES) for _ in range(N_ENSEMBLE)]
-            self.groups.append((len(sample_struct), len(members), prot))
-            sample_struct += members
-        self.n_structures = len(sample_struct)
-        self.structures = self.den.prepare_structures(xyz_list, z_list)
-        self.job = self.den.make_job(self.structures, sample_struct)
-        # decoder-side tables (host preprocessing in the reference: CG_nbr_list, info)
+        lengths, F, E = cfg["lengths"], cfg["n_frames"], cfg["n_ensemble"]
+        # weak scaling: every rank its own proteins (different seeds); strong: one job, same proteins everywhere
+        seed0 = 1000 if strong else 100 * rank + 1000
+        self.proteins = [synth.make_protein(L, seed0 + i, n_frames=F, phospho=cfg["vae_type"] != "N6")
+                         for i, L in enumerate(lengths)]
+        units = [(p, f, m) for p in range(len(lengths)) for f in range(F) for m in range(E)]
+        self.n_units_job = len(units)
+        self.job_flop = sum(algorithmic_flop_per_structure(lengths[p]) for p, _f, _m in units)
+        if strong:
+            costs = [parallel.unit_cost(lengths[p]) for p, _f, _m in units]
+            parts = cfg.get("share_of") or world
+            shard = parallel.shard_units(costs, parts)[rank if not cfg.get("share_of") else 0]
+            units = [units[u] for u in shard]
+            if cfg.get("share_of"):
+                self.n_units_job = len(units)
+                self.job_flop = sum(algorithmic_flop_per_structure(lengths[p]) for p, _f, _m in units)
+        self.units = units                                   # sorted by (protein, frame, member)
+        s_key = sorted({u[:2] for u in units})
+        s_of = {k: i for i, k in enumerate(s_key)}
+        xyz_list = [torch.from_numpy(self.proteins[p]["xyz_full"])[f, 1:-1] for p, f in s_key]
+        z_list = [torch.from_numpy(self.proteins[p]["z_full"])[1:-1] for p, _f in s_key]
+        self.structures = self.den.new_structures(xyz_list, z_list)
+        self.job = self.den.make_job(self.structures, [s_of[u[:2]] for u in units])
+        self.n_structures = len(units)
+        # decoder-side tables (host preprocessing in the reference: batch dict, info)
         ni = self.job.node_info
         self.cg_z = ni[:, 3].contiguous()
         self.cg_xyz = self.structures.xyz[ni[:, 0].long()].contiguous()
-        self.csr = self.dec.build_csr(self.cg_xyz, self.job.sample_lens)   # CG graph within 21 A, on the device
+        self.sample_range = self.dec.sample_ranges(self.job.sample_lens)
+        self.max_dir_edges = int(sum(L * (L - 1) for L in self.job.sample_lens))
         self.n_edges = int(ni[:, 2].sum())
-        self.ca_full = []
-        for start, count, prot in self.groups:
-            frames = torch.from_numpy(prot["xyz_full"]).to(device)
-            idx = torch.arange(N_FRAMES, device=device).repeat_interleave(N_ENSEMBLE)
-            self.ca_full.append(frames[idx].contiguous())
+        self.groups = []                                     # (first sample, count, protein, ca_full [count, L+2, 3])
+        k = 0
+        while k < len(units):
+            p = units[k][0]
+            k2 = k
+            while k2 < len(units) and units[k2][0] == p:
+                k2 += 1
+            frames = torch.from_numpy(self.proteins[p]["xyz_full"]).to(device)
+            idx = torch.tensor([u[1] for u in units[k:k2]], device=device)
+            self.groups.append((k, k2 - k, self.proteins[p], frames[idx].contiguous()))
+            k = k2
         g = torch.Generator(device=device)
         g.manual_seed(42 + rank)
-        self.x_T = torch.randn(self.job.n_nodes, 3, generator=g, device=device)
-        self.noise = torch.randn(T_STEPS, self.job.n_nodes, 3, generator=g, device=device)
-        self.flop = sum(N_FRAMES * N_ENSEMBLE * algorithmic_flop_per_structure(L) for L in PED_LENGTHS)
+        n = self.job.n_nodes
+        if self.decode_only:
+            self.latent = torch.randn(n, 3, generator=g, device=device)      # normalised, stands in for the encoder
+        else:
+            self.x_T = torch.randn(n, 3, generator=g, device=device)
+            self.noise = torch.randn(T_STEPS, n, 3, generator=g, device=device)
+        if not strong:
+            self.job_flop *= world
+
+    def prepass(self):
+        """Per-structure and per-job work the reference redoes in every step (CA features, adaLN vectors) or on
+        the host (CG neighbour list): kernels only, tables and buffers were made in __init__."""
+        if not self.decode_only:
+            self.den.compute_features(self.structures)
+            self.den.step_mods(self.tables.timestep_map, refresh=True)
+        self.csr = self.dec.build_csr(self.cg_xyz, self.job.sample_lens, sample_range=self.sample_range,
+                                      max_edges=self.max_dir_edges)
 
     def run(self):
-        """noise (HBM) -> all-atom coordinates (HBM) for the 400 structures."""
-        x0 = self.den.sample(self.job, self.x_T, self.noise, self.tables)
+        """CA traces + noise (HBM) -> all-atom coordinates (HBM) for this rank's structures."""
+        self.prepass()
+        x0 = self.latent if self.decode_only else self.den.sample(self.job, self.x_T, self.noise, self.tables)
         idx, zq, _lat = self.dec.vq(x0)
         ic = self.dec.ic_decode(zq, self.cg_z, self.cg_xyz, csr=self.csr)
         out = []
-        for (start, count, prot), ca in zip(self.groups, self.ca_full):
+        for start, count, prot, ca in self.groups:
             L = prot["n_cg"]
             a = int(self.job.sample_off[start])
             b = int(self.job.sample_off[start + count])
             out.append(self.dec.ic_to_xyz(ca, ic[a:b].view(count, L, 13, 3), prot["info"]))
         return out, idx
 
+    def timed(self, fn, n=1):
+        """Average wall time of fn() in seconds by HIP events on the stream the kernels are enqueued on."""
+        stream = torch.cuda.current_stream(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
     def time_dominant_kernel(self, n_launch=20):
         """Average duration of one message-kernel launch (encoder layer 1: both GEMM layers over
         every edge of the job, edge state read from HBM - what 5 of the 6 message launches of a step
-        look like), HIP events on the stream the kernel runs on."""
+        look like) and of one edge-update launch, HIP events on the stream the kernels run on."""
         from codlad_amd import _lib
         lib = _lib.lib()
         stream = torch.cuda.current_stream(self.device)
@@ -124,21 +183,26 @@ class Workload:
         for which, name in ((0, "message"), (1, "edge_update")):
             for _ in range(3):
                 launch(which)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(n_launch):
-                launch(which)
-            e1.record(stream)
-            e1.synchronize()
-            res[name] = e0.elapsed_time(e1) / n_launch * 1e-3
+            res[name] = self.timed(lambda: launch(which), n_launch)
         return res
 
 
-def cpu_baseline():
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name):
     """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample: 4 frames of
     the L=87 protein, 20 of the 100 DDPM steps run as the reference runs them (batch duplicated,
     test.py:505; CA features recomputed every step), plus the decoder tail; extrapolated linearly
-    to 100 steps (every step costs the same)."""
+    to 100 steps (every step costs the same).  cfg5: the decoder tail alone."""
     from codlad_amd import synth
     from oracle import denoiser as oden, sampler as osam, vae_decode as odec
     torch.set_grad_enabled(False)
@@ -159,13 +223,25 @@ def cpu_baseline():
     dup = lambda t: torch.cat([t, t])  # noqa: E731
     z = synth.gaussian((2 * B, L, 3), 1)
     eps = synth.gaussian((Tsub, 2 * B, L, 3), 2)
+    common = {"unit": "structures/s", "cores": cores, "kind": "port", "cpu_model": cpu_model()}
+
+    def decode(x):
+        t0 = time.perf_counter()
+        idx, ic = odec.latent_decode(vsd, odec.denormalise(x, mean, std), batch)
+        odec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4), ic.reshape(-1, L, 13, 3), prot["info"])
+        return time.perf_counter() - t0
+
+    if cfg_name == "cfg5":
+        decode(z[:B])
+        reps = 20
+        t_dec = sum(decode(z[:B]) for _ in range(reps)) / reps
+        return dict(common, value=B / t_dec,
+                    sample=f"oracle (PyTorch-CPU fp32, {cores} threads): decoder tail only (de-normalise + VQ + "
+                           f"IC_Decoder + ic_to_xyz) on L=87, {B} frames, mean of {reps} runs: {t_dec * 1e3:.1f} ms")
     t0 = time.perf_counter()
     x = osam.p_sample_loop(sd, Tsub, z, eps, dup(cg_xyz), dup(cg_z), dup(mask))
     t_loop = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    idx, ic = odec.latent_decode(vsd, odec.denormalise(x[:B], mean, std), batch)
-    odec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4), ic.reshape(-1, L, 13, 3), prot["info"])
-    t_dec = time.perf_counter() - t0
+    t_dec = decode(x[:B])
     per_struct = (t_loop * (T_STEPS / Tsub) + t_dec) / B
     # the same work without the reference's redundancy (no duplicated batch, features once): what a
     # tuned CPU run of this algorithm would do, reported beside the headline baseline
@@ -173,11 +249,25 @@ def cpu_baseline():
     osam.p_sample_loop(sd, Tsub, z[:B], eps[:, :B], cg_xyz, cg_z, mask, hoist_features=True)
     t_dedup = time.perf_counter() - t0
     dedup = 1.0 / ((t_dedup * (T_STEPS / Tsub) + t_dec) / B)
-    return {"value": 1.0 / per_struct, "unit": "structures/s", "cores": cores, "kind": "port",
-            "value_deduplicated": dedup,
-            "sample": f"oracle (PyTorch-CPU fp32, {cores} threads): L=87, {B} frames, {Tsub} of {T_STEPS} DDPM steps "
-                      f"as the reference runs them (2x duplicated batch, features recomputed per step) + decode, "
-                      f"extrapolated x{T_STEPS // Tsub}; {t_loop:.2f}s loop + {t_dec:.3f}s decode"}
+    return dict(common, value=1.0 / per_struct, value_deduplicated=dedup,
+                sample=f"oracle (PyTorch-CPU fp32, {cores} threads): L=87, {B} frames, {Tsub} of {T_STEPS} DDPM steps "
+                       f"as the reference runs them (2x duplicated batch, features recomputed per step) + decode, "
+                       f"extrapolated x{T_STEPS // Tsub}; {t_loop:.2f}s loop + {t_dec:.3f}s decode")
+
+
+def committed_traffic(cfg_name, precision):
+    """HBM bytes per launch of the dominant kernel.  PMC counters need rocprofv3 around the process, so the
+    figure comes from the newest committed profile of this same workload and kernel (profiles/README.md says
+    how it was taken) and is tagged with its source; null for workloads that have no such profile."""
+    if cfg_name != "cfg2" or precision != "f16x3":
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    finals = [f for f in files if "_mid_" not in f]
+    if not finals:
+        return None, None
+    with open(finals[-1]) as f:
+        d = json.load(f)
+    return d["hbm_bytes_per_launch"], f"profiles/{os.path.basename(finals[-1])} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {d['kernel']})"
 
 
 def main():
@@ -185,7 +275,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg4share", "cfg5"], default="cfg2",
+                    help="BASELINE.json configuration (default cfg2, the one the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA timing of the same job")
     ap.add_argument("--precision", choices=["f16x3", "f16x4", "f32"], default="f16x3",
                     help="contraction mode: f16x3 (default) / f16x4 = fp32 operands split into fp16 hi+lo halves on "
                          "the f16 matrix pipe, 3 or 4 cross products per fp32 product, fp32 accumulation "
@@ -200,6 +293,8 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.config == "cfg4share" and world != 1:
+        raise SystemExit("cfg4share is one GPU's eighth of cfg4: run it with --gpus 1, or run --config cfg4 --gpus N")
     torch.set_grad_enabled(False)
     backend = os.environ.get("CODLAD_DIST_BACKEND", "nccl")   # "gloo": rehearsal of N > 1 on a one-GPU box
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
@@ -214,7 +309,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    wl = Workload(device, rank, args.precision)
+    wl = Workload(device, args.config, rank, world, args.precision)
     if world > 1:
         # weights travel once, rank 0 -> all, as one buffer each (RCCL broadcast over xGMI)
         from codlad_amd.parallel import broadcast_weights
@@ -232,65 +327,102 @@ def main():
             gather_coordinates(xyz, world)
         return xyz
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    def timed_steps(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        return dt
 
-    kern = wl.time_dominant_kernel()
-    # HBM bytes per launch of the dominant kernel: PMC counters need rocprofv3, so the figure comes from
-    # the committed profile of this same workload (profiles/README.md says how it was taken)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
-    if args.precision != "f32" and os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+    dt = timed_steps(args.warmup, args.steps)
+    strong = wl.cfg["scaling"] == "strong"
+    structs_per_step = wl.n_units_job if strong else wl.n_structures * world
+
+    extra = {}
+    if rank == 0 and world == 1:
+        extra["prepass_ms"] = wl.timed(wl.prepass, 3) * 1e3     # share of ms_per_step spent before the first DDPM step
+    if not wl.decode_only:
+        kern = wl.time_dominant_kernel()
+        if world == 1 and args.precision != "f32" and not args.no_f32_leg:
+            # the same job, same weights, contractions on the fp32 matrix instruction (IEEE fp32 products)
+            wl.den.weights.set_precision("f32")
+            dt32 = timed_steps(1, 1)
+            k32 = wl.time_dominant_kernel(5)
+            wl.den.weights.set_precision(args.precision)
+            extra["f32_mfma"] = {"value": structs_per_step / dt32, "unit": "structures/s", "ms_per_step": dt32 * 1e3,
+                                 "launch_ms": k32["message"] * 1e3, "steps": 1, "warmup": 1,
+                                 "note": "same job and weights with every contraction on v_mfma_f32_32x32x2_f32; "
+                                         "roofline of that mode: algorithmic FLOP / launch / 157.3 TFLOP/s = "
+                                         f"{2.0 * (384 * 128 + 128 * 128) * wl.n_edges / k32['message'] / 1e12 / FP32_MFMA_PEAK_TFLOPS:.3f}"
+                                         " (above 1 is possible: the W1 split removes half of the algorithmic MACs)"}
     if rank == 0:
-        total_structs = wl.n_structures * world * args.steps
-        value = total_structs / dt
-        # dominant kernel: layers 1-2 of the encoder message MLP, algorithmic 2*(384*128 + 128*128)
-        # FLOP per edge (reference protein_mpnn_utils.py:240-243; W3 runs in the node kernel)
-        flop_launch = 2.0 * (384 * 128 + 128 * 128) * wl.n_edges
+        value = structs_per_step * args.steps / dt
         terms = {"f16x3": 3, "f16x4": 4, "f32": 0}[args.precision]
-        achieved = flop_launch / kern["message"] / 1e12
+        if wl.decode_only:
+            # HBM / latency-bound tail: the whole decode (CG graph, VQ, IC decoder, ic_to_xyz) as one unit
+            t_dec = wl.timed(wl.run, 5)
+            n_atoms = sum(c * int(p["info"][0].numel()) for _s, c, p, _ca in wl.groups)
+            nbytes = sum(decode_bytes_per_structure(L, 0, 0) for L in wl.job.sample_lens) + 20 * n_atoms + \
+                16 * int(wl.csr[0][-1]) // 2
+            roofline = {"bound": "hbm", "achieved": nbytes / t_dec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": nbytes / t_dec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "cg_graph + vq + dec_init/msg/heads + ic_to_xyz (the whole decode, launch-latency bound)",
+                        "launch_ms": t_dec * 1e3, "algorithmic_bytes_per_launch": nbytes}
+        else:
+            # dominant kernel: layers 1-2 of the encoder message MLP.  Algorithmic 2*(384*128 + 128*128) FLOP per
+            # edge (reference protein_mpnn_utils.py:240-243; W3 runs in the node kernel); EXECUTED after the W1
+            # split: two 128x128 contractions per edge, each product as `terms` f16 MFMA products.
+            alg = 2.0 * (384 * 128 + 128 * 128) * wl.n_edges
+            exe = 2.0 * 2 * 128 * 128 * wl.n_edges
+            traffic, traffic_src = committed_traffic(args.config, args.precision)
+            if terms:
+                achieved, peak = terms * exe / kern["message"] / 1e12, F16_MFMA_PEAK_TFLOPS
+                pipe = f"f16 matrix pipe (v_mfma_f32_32x32x16_f16), {terms} MFMA products per fp32 product"
+            else:
+                achieved, peak = exe / kern["message"] / 1e12, FP32_MFMA_PEAK_TFLOPS
+                pipe = "fp32 matrix instruction (v_mfma_f32_32x32x2_f32)"
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                        "pipe": pipe,
+                        "kernel": ("msg_kernel_h " if terms else "edge_kernel<false> ") + "(encoder message MLP, layers 1-2)",
+                        "launch_ms": kern["message"] * 1e3,
+                        "flop_note": "achieved = matrix-pipe FLOP the launch EXECUTES / HIP-event time (what the pipe is "
+                                     "busy with); the algebraic W1 split halves the algorithmic MACs of SURVEY.md 8d, so "
+                                     "algorithmic figures are listed separately and never divided into this peak",
+                        "executed_pipe_flop_per_launch": (terms or 1) * exe,
+                        "algorithmic_flop_per_launch": alg,
+                        "algorithmic_tflops": alg / kern["message"] / 1e12,
+                        "algorithmic_over_fp32_mfma_peak": alg / kern["message"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "edge_update_launch_ms": kern["edge_update"] * 1e3,
+                        "whole_job_algorithmic_tflops": wl.job_flop * args.steps / dt / 1e12}
         result = {
-            "metric": "sampled all-atom structures/sec (100-step DDPM, PED)",
+            "metric": "sampled all-atom structures/sec (100-step DDPM, PED)" if args.config == "cfg2" else
+                      f"sampled all-atom structures/sec ({args.config})",
             "value": value, "unit": "structures/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "precision": (f"{args.precision}: fp32 operands split into fp16 hi+lo (|eps| <= 2^-22), {terms} f16 MFMAs "
-                          "per product, fp32 accumulate; all other arithmetic fp32" if terms else
-                          "f32: v_mfma_f32_32x32x2_f32, all arithmetic fp32"),
-            "config": {"workload": "cfg2: PED-shaped test set, 4 proteins L=46/87/92/129 x 10 frames x "
-                                   "num_ensemble 10 = 400 structures per GPU, 100-step DDPM (mpnn_diffusion) + "
-                                   "VQ(4096x3) + IC_Decoder N6 + ic_to_xyz",
-                       "structures_per_gpu": wl.n_structures, "nodes_per_gpu": wl.job.n_nodes,
-                       "edges_per_gpu": wl.n_edges, "ddpm_steps": T_STEPS, "parallelism": f"replicas x{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("msg_kernel_h " if terms else "edge_kernel<false> ") +
-                                   "(encoder message MLP, layers 1-2)",
-                         "peak_note": "fp32 matrix peak of MI355X_MICROARCH.md; algorithmic FLOP of SURVEY.md 8d "
-                                      "(the kernel executes half of them after the W1 split, and in the split-fp16 "
-                                      "modes runs them on the f16 pipe), so frac may exceed 1",
-                         "f16_pipe_frac": (terms * 2.0 * 2 * 128 * 128 * wl.n_edges / kern["message"] / 2.5e15
-                                           if terms else None),
-                         "launch_ms": kern["message"] * 1e3,
-                         "algorithmic_flop_per_launch": flop_launch,
-                         "executed_flop_per_launch": 2.0 * 2 * 128 * 128 * wl.n_edges,
-                         "edge_update_launch_ms": kern["edge_update"] * 1e3,
-                         "whole_job_algorithmic_tflops": wl.flop * world * args.steps / dt / 1e12},
+            "scaling": wl.cfg["scaling"], "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+            "precision": args.precision,
+            "config": {"workload": wl.cfg["what"],
+                       "structures_per_step": structs_per_step, "structures_rank0": wl.n_structures,
+                       "nodes_rank0": wl.job.n_nodes, "edges_rank0": wl.n_edges, "ddpm_steps": 0 if wl.decode_only else T_STEPS,
+                       "timed_region": "CA traces + noise in HBM -> xyz in HBM: features + layer-0 edge terms + adaLN "
+                                       "vectors + CG graph + DDPM loop + VQ + IC decode + ic_to_xyz"
+                                       + (" + all-gather of coordinates" if world > 1 else ""),
+                       "parallelism": (f"units sharded x{world} (LPT), no data-path collective" if strong
+                                       else f"replicas x{world}")},
+            "roofline": roofline,
         }
+        result.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 4   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -48,7 +48,7 @@ class DenoiserWeights(C.Structure):
 
 
 class Workspace(C.Structure):
-    _fields_ = [(n, P) for n in ("hV", "hVenc", "S", "PQ", "hE")]
+    _fields_ = [(n, P) for n in ("hV", "hVenc", "S", "PQ", "hE", "status")]
 
 
 class DecoderWeights(C.Structure):
@@ -82,6 +82,7 @@ _SIGS = {
     "codlad_layer0_edge_terms": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P]),
     "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P,
                                           C.POINTER(Workspace), P]),
+    "codlad_status_check": (C.c_int, [P, P]),
     "codlad_ddpm_update": (C.c_int, [P, P, P, P, C.c_int, P, P, P]),
     "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P, P,
                                      C.c_int, C.POINTER(Workspace), P]),

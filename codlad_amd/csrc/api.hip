@@ -15,8 +15,16 @@ void codlad_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+hipError_t codlad_take_attr_error();   // denoiser_kernels.hip: a failed hipFuncSetAttribute, if any
+
 int codlad_check_launch(const char *what) {
-    hipError_t e = hipGetLastError();
+    hipError_t e = codlad_take_attr_error();
+    if (e != hipSuccess) {
+        codlad_set_error("%s: raising the dynamic LDS limit of a kernel failed: %s", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return (int)e;
+    }
+    e = hipGetLastError();
     if (e != hipSuccess) {
         codlad_set_error("%s: %s", what, hipGetErrorString(e));
         return (int)e;

@@ -637,6 +637,7 @@ struct FinalArgs {
     const float *noise; // [n][3]
     const float *coef;  // device [8]
     float *x_start;     // [n][3] or null: pred_xstart of this step (self-conditioning input of the next)
+    int *status;        // sticky status word or null (CODLAD_STATUS_NONFINITE)
 };
 
 __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
@@ -673,6 +674,14 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] += a.out_b[k];
+    if (a.status) {
+        // inf / NaN by exponent bits: this file is built with -fno-honor-nans, which lets the compiler
+        // fold a floating-point self-comparison away; an integer test it cannot
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bad |= (__float_as_uint(o[k]) & 0x7f800000u) == 0x7f800000u;
+        if (bad) atomicOr(a.status, CODLAD_STATUS_NONFINITE);
+    }
     if (a.logits) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) a.logits[(size_t)n * 6 + k] = o[k];
@@ -764,6 +773,20 @@ static int num_cu() {
 }
 
 // precision: 0 = fp32 MFMA, 1 = f16x4, 2 = f16x3 (include/codlad_hip.h)
+// Raising a kernel's dynamic-LDS limit can fail (e.g. a device with less LDS than gfx950's 160 KB); the
+// launch that follows would then fail with a less telling error, so the failure is kept for
+// codlad_check_launch to report.
+static hipError_t g_attr_error = hipSuccess;
+static void set_max_lds(const void *fn, size_t bytes) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess && g_attr_error == hipSuccess) g_attr_error = e;
+}
+hipError_t codlad_take_attr_error() {
+    const hipError_t e = g_attr_error;
+    g_attr_error = hipSuccess;
+    return e;
+}
+
 template <int TERMS>
 static void launch_edge_h(bool update, const EdgeArgs &ea, hipStream_t st) {
     static bool attr_set = false;     // one flag per TERMS instantiation
@@ -776,8 +799,8 @@ static void launch_edge_h(bool update, const EdgeArgs &ea, hipStream_t st) {
         const void *upd[2] = {reinterpret_cast<const void *>(upd_kernel_h<UPD_WAVES, false, TERMS>),
                               reinterpret_cast<const void *>(upd_kernel_h<UPD_WAVES, true, TERMS>)};
         for (int i = 0; i < 2; ++i) {
-            (void)hipFuncSetAttribute(msg[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msg);
-            (void)hipFuncSetAttribute(upd[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd);
+            set_max_lds(msg[i], lds_msg);
+            set_max_lds(upd[i], lds_upd);
         }
         attr_set = true;
     }
@@ -808,10 +831,8 @@ static void launch_node_hw(bool upd, const NodeArgs &na, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = 2 * 65536 + 4 * 512;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<true, NW, TERMS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(node_kernel_h<false, NW, TERMS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_max_lds(reinterpret_cast<const void *>(node_kernel_h<true, NW, TERMS>), lds);
+        set_max_lds(reinterpret_cast<const void *>(node_kernel_h<false, NW, TERMS>), lds);
         attr_set = true;
     }
     static_assert(NODE_WG_TILE % (32 * NW) == 0, "chunks hold whole workgroup tiles");
@@ -962,7 +983,7 @@ extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const i
     enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, x_self_cond, mods_t, ws, st);
     FinalArgs fa = {};
     fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
-    fa.n_nodes = n_nodes; fa.logits = out;
+    fa.n_nodes = n_nodes; fa.logits = out; fa.status = ws->status;
     hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
     return codlad_check_launch("codlad_denoiser_forward");
 }
@@ -1000,10 +1021,29 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
         FinalArgs fa = {};
         fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
         fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
-        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start;
+        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start; fa.status = ws->status;
         hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
     }
     return codlad_check_launch("codlad_sample_loop");
+}
+
+extern "C" int codlad_status_check(int32_t *status, void *stream) {
+    CODLAD_REQUIRE(status, "null pointer");
+    int32_t host = 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(&host, status, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && host) e = hipMemsetAsync(status, 0, sizeof(host), st);
+    if (e != hipSuccess) {
+        codlad_set_error("codlad_status_check: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    if (host & CODLAD_STATUS_NONFINITE) {
+        codlad_set_error("denoiser output is not finite: an input, a weight or - in the split-fp16 contraction "
+                         "modes - an operand beyond the fp16 range (|x| > 65504) overflowed; rerun with precision f32 to tell them apart");
+        return CODLAD_E_NONFINITE;
+    }
+    return 0;
 }
 
 // Hoisted layer-0 edge terms: W1e(enc 0) @ h_E0 and W11e(enc 0) @ h_E0 per structure edge.  h_E0

@@ -80,8 +80,10 @@ class Job:
         self.S = torch.empty(n, H, **f32)
         self.PQ = torch.empty(4, n, H, **f32)
         self.hE = torch.empty(n, KNN, H, **f32)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)   # sticky flags (CODLAD_STATUS_*)
         ws = _lib.Workspace()
-        ws.hV, ws.hVenc, ws.S, ws.PQ, ws.hE = (_lib.ptr(t) for t in (self.hV, self.hVenc, self.S, self.PQ, self.hE))
+        ws.hV, ws.hVenc, ws.S, ws.PQ, ws.hE, ws.status = (
+            _lib.ptr(t) for t in (self.hV, self.hVenc, self.S, self.PQ, self.hE, self.status))
         self.ws = ws
 
     def workspace_bytes(self):
@@ -100,32 +102,44 @@ class Denoiser:
         self._mods_cache = {}
 
     # -- step-invariant part -------------------------------------------------------------------
-    def prepare_structures(self, xyz_list, z_list, hoist_layer0=True):
-        """k-NN graph + h_E0 per structure, and (hoist_layer0) the two layer-0 contractions of h_E0,
-        which are the same in every step and for every ensemble member (costs 2x the h_E0 memory)."""
+    def new_structures(self, xyz_list, z_list, hoist_layer0=True):
+        """Tables of a set of structures uploaded and the buffers of their step-invariant part
+        allocated; `compute_features` fills them (split so that a caller can time the kernels apart
+        from the uploads, bench.py)."""
         st = Structures(xyz_list, z_list, self.device)
         st.E_idx = torch.empty(st.n_snodes, KNN, dtype=torch.int32, device=self.device)
         st.h_E0 = torch.empty(st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
+        if hoist_layer0:
+            st.E1 = torch.empty(2, st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
+        return st
+
+    def compute_features(self, st):
+        """k-NN graph + h_E0 per structure (codlad_features_prepass), and - when the structures were
+        made with hoist_layer0 - the two layer-0 contractions of h_E0, which are the same in every
+        step and for every ensemble member (costs 2x the h_E0 memory).  Only enqueues kernels."""
         rc = self.lib.codlad_features_prepass(C.byref(self.weights.struct), _lib.ptr(st.xyz),
                                               _lib.ptr(st.snode_info), st.n_snodes, max(st.lens),
                                               _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
                                               _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_features_prepass")
-        if hoist_layer0:
-            st.E1 = torch.empty(2, st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
+        if st.E1 is not None:
             rc = self.lib.codlad_layer0_edge_terms(C.byref(self.weights.struct), _lib.ptr(st.snode_info),
                                                    st.n_snodes, _lib.ptr(st.h_E0), _lib.ptr(st.E1),
                                                    _lib.stream_ptr(self.device))
             _lib.check(rc, "codlad_layer0_edge_terms")
         return st
 
+    def prepare_structures(self, xyz_list, z_list, hoist_layer0=True):
+        return self.compute_features(self.new_structures(xyz_list, z_list, hoist_layer0))
+
     def make_job(self, structures, sample_struct):
         return Job(structures, sample_struct, self.device)
 
-    def step_mods(self, t_values):
-        """[len(t_values), 6016] adaLN modulation vectors; cached per timestep list."""
+    def step_mods(self, t_values, refresh=False):
+        """[len(t_values), 6016] adaLN modulation vectors; cached per timestep list (refresh: run the
+        kernel again even if cached)."""
         key = tuple(int(t) for t in t_values)
-        if key not in self._mods_cache:
+        if refresh or key not in self._mods_cache:
             tv = torch.tensor(key, dtype=torch.int64, device=self.device)
             mods = torch.empty(len(key), MODS, dtype=torch.float32, device=self.device)
             rc = self.lib.codlad_step_mods(C.byref(self.weights.struct), _lib.ptr(tv), len(key),
@@ -141,9 +155,16 @@ class Denoiser:
     def self_condition(self):
         return self.weights.self_condition
 
-    def forward(self, job, x, t_value, x_self_cond=None):
+    def check_status(self, job):
+        """Wait for the job's stream and raise if a forward produced inf / NaN (in the split-fp16 modes:
+        also if an operand left the fp16 range, include/codlad_hip.h CODLAD_STATUS_NONFINITE)."""
+        _lib.check(self.lib.codlad_status_check(_lib.ptr(job.status), _lib.stream_ptr(self.device)),
+                   "codlad_status_check")
+
+    def forward(self, job, x, t_value, x_self_cond=None, check=True):
         """One denoiser call: x [n_nodes,3] -> [n_nodes,6] (eps | variance logits).  x_self_cond
-        [n_nodes,3]: previous pred_xstart, for a self-conditioned model only (None = zeros)."""
+        [n_nodes,3]: previous pred_xstart, for a self-conditioned model only (None = zeros).
+        check: synchronise and raise on a non-finite output."""
         _require_cuda(x, "x")
         x = x.contiguous().float()
         assert x.shape == (job.n_nodes, 3)
@@ -162,11 +183,14 @@ class Denoiser:
                                               _lib.ptr(mods), _lib.ptr(out), C.byref(job.ws),
                                               _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_denoiser_forward")
+        if check:
+            self.check_status(job)
         return out
 
-    def sample(self, job, x_T, noise, tables):
+    def sample(self, job, x_T, noise, tables, check=True):
         """Full ancestral loop.  x_T [n_nodes,3]; noise [T,n_nodes,3] in loop order (first entry
-        is used at step T-1); tables = diffusion_and_flow.schedule.Tables.  Returns x_0."""
+        is used at step T-1); tables = diffusion_and_flow.schedule.Tables.  Returns x_0.
+        check: after the loop, synchronise and raise if any step's output was not finite."""
         _require_cuda(x_T, "x_T")
         _require_cuda(noise, "noise")
         T = tables.num_timesteps
@@ -183,6 +207,8 @@ class Denoiser:
                                          _lib.ptr(noise), _lib.ptr(mods), _lib.ptr(coef), T, C.byref(job.ws),
                                          _lib.stream_ptr(self.device))
         _lib.check(rc, "codlad_sample_loop")
+        if check:
+            self.check_status(job)
         return x
 
     def ddpm_update(self, x, model_out, noise, tables, i, return_x_start=False):
@@ -246,42 +272,54 @@ class Decoder:
         ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         return ptr, src
 
-    def build_csr(self, cg_xyz, sample_lens, cutoff=21.0):
+    def build_csr(self, cg_xyz, sample_lens, cutoff=21.0, sample_range=None, max_edges=None):
         """Directed CG graph of every sample as CSR, on the device (what the reference's host
         preprocessing + make_directed + scatter order amount to).  cg_xyz [M,3] flat over samples,
         sample_lens: residues per sample."""
         xyz = cg_xyz.to(self.device).contiguous().float()
         M = xyz.shape[0]
-        assert sum(sample_lens) == M
-        rng = np.empty((M, 2), dtype=np.int32)
-        o = 0
-        for L in sample_lens:
-            rng[o:o + L, 0] = o
-            rng[o:o + L, 1] = L
-            o += L
-        rng = torch.from_numpy(rng).to(self.device)
+        rng = self.sample_ranges(sample_lens) if sample_range is None else sample_range
+        assert rng.shape == (M, 2)
         deg = torch.empty(M, dtype=torch.int32, device=self.device)
         st = _lib.stream_ptr(self.device)
         _lib.check(self.lib.codlad_cg_graph(_lib.ptr(xyz), _lib.ptr(rng), M, C.c_float(cutoff), _lib.ptr(deg),
                                             None, None, st), "codlad_cg_graph(count)")
         ptr = torch.zeros(M + 1, dtype=torch.int32, device=self.device)
         ptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
-        src = torch.empty(max(int(ptr[-1]), 1), dtype=torch.int32, device=self.device)
+        # max_edges (an upper bound on the directed edge count, e.g. sum L*(L-1)) avoids the host
+        # round trip that sizes csr_src exactly; the tail past ptr[-1] is then simply unused
+        n_src = max_edges if max_edges is not None else int(ptr[-1])
+        src = torch.empty(max(n_src, 1), dtype=torch.int32, device=self.device)
         _lib.check(self.lib.codlad_cg_graph(_lib.ptr(xyz), _lib.ptr(rng), M, C.c_float(cutoff), None,
                                             _lib.ptr(ptr), _lib.ptr(src), st), "codlad_cg_graph(fill)")
-        return ptr, src[:int(ptr[-1])]
+        return ptr, src[:n_src]
+
+    def sample_ranges(self, sample_lens):
+        """[M,2] int32 device table {first node, L} of the sample each flat node belongs to."""
+        M = int(sum(sample_lens))
+        rng = np.empty((M, 2), dtype=np.int32)
+        o = 0
+        for L in sample_lens:
+            rng[o:o + L, 0] = o
+            rng[o:o + L, 1] = L
+            o += L
+        return torch.from_numpy(rng).to(self.device)
 
     def ic_decode(self, z_q, cg_z, cg_xyz, pairs=None, csr=None):
         """z_q [M,3], cg_z [M], cg_xyz [M,3] and either the undirected CG pairs [E,2] (flat node
         indices, as in batch['CG_nbr_list']) or a prebuilt csr = (ptr, src) -> ic [M,13,3]."""
         _require_cuda(z_q, "z_q")
         M = z_q.shape[0]
+        cg_z = cg_z.to(self.device, torch.int32).contiguous()
+        lo, hi = int(cg_z.min()), int(cg_z.max())
+        if lo < 0 or hi >= 25:      # res_embed / backbone_dist / sidechain_* tables have 25 rows (vae_model.py:330-345)
+            raise ValueError(f"cg_z (residue types {lo}..{hi}) outside the decoder's 25-row embedding tables")
         ptr, src = csr if csr is not None else self.csr_from_pairs(pairs.to(self.device), M)
         assert ptr.numel() == M + 1 and ptr.dtype == torch.int32 and src.dtype == torch.int32
         scratch = torch.empty(M, 200, dtype=torch.float32, device=self.device)
         ic = torch.empty(M, 13, 3, dtype=torch.float32, device=self.device)
         rc = self.lib.codlad_ic_decode(C.byref(self.weights.struct), _lib.ptr(z_q.contiguous().float()),
-                                       _lib.ptr(cg_z.to(self.device, torch.int32).contiguous()),
+                                       _lib.ptr(cg_z),
                                        _lib.ptr(cg_xyz.to(self.device).contiguous().float()),
                                        _lib.ptr(ptr), _lib.ptr(src), M, _lib.ptr(scratch), _lib.ptr(ic),
                                        _lib.stream_ptr(self.device))

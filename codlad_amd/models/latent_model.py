@@ -183,22 +183,17 @@ class ProteinMPNN_diffusion_new(nn.Module):
         t0 = int(tt[0])
         if tt.numel() > 1 and not bool((tt == t0).all()):
             raise NotImplementedError("per-sample timesteps: the sampler uses one timestep per call")
+        if len(set(lens)) != 1:
+            # the reference pads such a batch and its result then DIFFERS from each sample alone: K = min(64, L_max)
+            # and the decoder layers sum over padded neighbours (protein_mpnn_utils.py:304-307, mask_attend=None)
+            raise NotImplementedError("padded mixed-length batch: the reference's result for it depends on the "
+                                      "padding (K = min(64, L_max), unmasked decoder sums), which the ragged HIP "
+                                      "path does not reproduce; pass equal-length structures per call (what the "
+                                      "reference's loaders produce) or use codlad_amd.engine's ragged jobs")
         L = x.shape[1]
-        def ragged(v):
-            if len(set(lens)) == 1:
-                return v.reshape(-1, v.shape[-1])
-            return torch.cat([v[s, :n] for s, n in enumerate(lens * n_rep)], dim=0)   # padded mixed-length batch
-
-        flat = ragged(x)
-        out = self.engine().forward(job, flat, t0, None if x_self_cond is None else ragged(x_self_cond))
-        if len(set(lens)) == 1:
-            return out.view(N, L, -1)
-        res = out.new_zeros(N, L, out.shape[-1])
-        o = 0
-        for s, n in enumerate(lens * n_rep):
-            res[s, :n] = out[o:o + n]
-            o += n
-        return res
+        out = self.engine().forward(job, x.reshape(-1, x.shape[-1]), t0,
+                                    None if x_self_cond is None else x_self_cond.reshape(-1, x_self_cond.shape[-1]))
+        return out.view(N, L, -1)
 
 
 def mpnn_diffusion(**kwargs):

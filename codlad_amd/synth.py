@@ -114,6 +114,61 @@ def denoiser_state_dict(seed=1234, input_size=3, self_condition=False):
     return sd
 
 
+def _reference_module_plan(input_size=3):
+    """(name, kind, fan_in, fan_out, bias) of every parameterised submodule of the reference's
+    ProteinMPNN_diffusion_new in the order its constructor creates them (models/latent_model.py:119-148,
+    protein_mpnn_utils.py:208-235, 274-295, 321-344, 347-366; tools/gen_golden.py asserts the order)."""
+    plan = [("t_embedder.mlp.0", "linear", 256, H, True), ("t_embedder.mlp.2", "linear", H, H, True),
+            ("x_in", "linear", input_size, H, True),
+            ("features.embeddings.linear", "linear", 66, 16, True),
+            ("features.edge_embedding", "linear", 167, H, False), ("features.norm_edges", "layernorm", H, H, True),
+            ("W_e", "linear", H, H, True), ("W_s", "embedding", 30, H, False)]
+    for l in range(3):
+        p = f"encoder_layers.{l}"
+        plan += [(f"{p}.W1", "linear", 3 * H, H, True), (f"{p}.W2", "linear", H, H, True), (f"{p}.W3", "linear", H, H, True),
+                 (f"{p}.W11", "linear", 3 * H, H, True), (f"{p}.W12", "linear", H, H, True), (f"{p}.W13", "linear", H, H, True),
+                 (f"{p}.dense.W_in", "linear", H, 4 * H, True), (f"{p}.dense.W_out", "linear", 4 * H, H, True),
+                 (f"{p}.adaLN_modulation.1", "linear", H, 9 * H, True)]
+    for l in range(3):
+        p = f"decoder_layers.{l}"
+        plan += [(f"{p}.W1", "linear", 4 * H, H, True), (f"{p}.W2", "linear", H, H, True), (f"{p}.W3", "linear", H, H, True),
+                 (f"{p}.dense.W_in", "linear", H, 4 * H, True), (f"{p}.dense.W_out", "linear", 4 * H, H, True),
+                 (f"{p}.adaLN_modulation.1", "linear", H, 6 * H, True)]
+    plan += [("W_out.linear", "linear", H, 2 * input_size, True), ("W_out.adaLN_modulation.1", "linear", H, 2 * H, True)]
+    return plan
+
+
+def reference_init_state_dict(torch_seed=7, adaln_seed=99):
+    """The weights the REFERENCE CONSTRUCTOR itself produces under torch.manual_seed(torch_seed): PyTorch's
+    default Linear / Embedding init in construction order, then xavier_uniform_ on every parameter with more than
+    one dimension (models/latent_model.py:152-154) - replayed here on the same torch generator stream so that the
+    GPU box regenerates them without the reference (tools/gen_golden.py asserts bit-equality with the real
+    constructor).  The constructor zero-initialises the adaLN heads (:155-165), which would switch every gate off;
+    they get seeded non-zero values (adaln_seed) instead, as a trained model has."""
+    plan = _reference_module_plan()
+    sd = OrderedDict()
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(torch_seed)
+        mods = []
+        for name, kind, fi, fo, bias in plan:
+            m = {"linear": lambda: torch.nn.Linear(fi, fo, bias=bias), "embedding": lambda: torch.nn.Embedding(fi, fo),
+                 "layernorm": lambda: torch.nn.LayerNorm(fo)}[kind]()
+            mods.append((name, m))
+        for name, m in mods:
+            for pn, p in m.named_parameters():
+                if p.dim() > 1:
+                    torch.nn.init.xavier_uniform_(p)
+        for name, m in mods:
+            for pn, p in m.named_parameters():
+                sd[f"{name}.{pn}"] = p.detach().clone()
+    rng = _rng(adaln_seed)
+    for k in list(sd):
+        if "adaLN_modulation" in k:
+            shape = tuple(sd[k].shape)
+            sd[k] = _t(rng.standard_normal(shape) * (1.0 / np.sqrt(H) if len(shape) == 2 else 0.5))
+    return sd
+
+
 from .utils.dataset_module import _BUILTIN_STATS as NORM_STATS  # noqa: E402  (reference datasets/miu_and_sigma)
 
 
@@ -298,3 +353,49 @@ def make_batch(protein, frame_ids=None):
 
 def gaussian(shape, seed):
     return _t(_rng(seed).standard_normal(shape))
+
+
+# ----------------------------------------------------------------------------
+# BASELINE.json configurations as synthetic workloads
+# ----------------------------------------------------------------------------
+PED_LENGTHS = (46, 87, 92, 129)
+
+
+def atlas_test_lengths():
+    """The `seqlen` column of the reference's Atlas test list (datasets/protein/Atlas/new_atlas_test.csv:
+    70 proteins, 39..505 residues, median 155), kept as a data fixture (tools/gen_golden.py g0)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        "atlas_test_seqlen.json")
+    with open(path) as f:
+        return [int(x) for x in json.load(f)["seqlen"]]
+
+
+def baseline_config(name):
+    """name -> dict(lengths, n_frames, n_ensemble, vae_type, dataname, decode_only, scaling, what).
+    cfg2..cfg5 are BASELINE.json configs[1..4] with the sizes SURVEY.md §8(d) fixes; PDB lengths do not ship
+    with the reference, so cfg3 takes the first 64 Atlas test lengths clipped to 50..400 (as §8d says)."""
+    if name in ("cfg2", "cfg5"):
+        return dict(lengths=list(PED_LENGTHS), n_frames=10, n_ensemble=10, vae_type="N6", dataname="PED",
+                    decode_only=name == "cfg5", scaling="weak",
+                    what=("cfg2: PED-shaped test set, 4 proteins L=46/87/92/129 x 10 frames x num_ensemble 10 = 400 "
+                          "structures per GPU, 100-step DDPM (mpnn_diffusion) + VQ(4096x3) + IC_Decoder N6 + ic_to_xyz"
+                          if name == "cfg2" else
+                          "cfg5: --experiment recon on the cfg2 geometry (400 structures per GPU): VQ(4096x3) + IC_Decoder "
+                          "N6 + ic_to_xyz only, latents drawn N(mean, std) in place of the e3nn encoder's"))
+    if name == "cfg3":
+        lengths = [max(50, min(400, L)) for L in atlas_test_lengths()[:64]]
+        return dict(lengths=lengths, n_frames=1, n_ensemble=1, vae_type="K3", dataname="PDB", decode_only=False,
+                    scaling="strong",
+                    what="cfg3: 64 proteins (Atlas test lengths clipped to 50..400), 1 frame each, 100-step DDPM + "
+                         "VQ + IC_Decoder_angle K3 + ic_to_xyz, units sharded over the GPUs (LPT)")
+    if name in ("cfg4", "cfg4share"):
+        return dict(lengths=atlas_test_lengths(), n_frames=4, n_ensemble=32, vae_type="K4", dataname="Atlas",
+                    decode_only=False, scaling="strong", share_of=8 if name == "cfg4share" else None,
+                    what=("cfg4: Atlas test set, 70 proteins (39..505 residues) x 4 frames x num_ensemble 32 = 8960 "
+                          "structures, 100-step DDPM + VQ + IC_Decoder_angle K4 + ic_to_xyz, units sharded over the "
+                          "GPUs (LPT), coordinates all-gathered" +
+                          ("; THIS RUN: the 1/8 share (1120 structures) LPT deals to rank 0 of 8" if name == "cfg4share"
+                           else "")))
+    raise KeyError(name)

@@ -53,11 +53,19 @@ def _pack_index_h():
 _ROWS_H, _COLS_H = _pack_index_h()
 
 
+FP16_MAX = 65504.0
+
+
 def pack_block_h(w, scale=1.0):
     """[128,128] block -> hi/lo fp16 split in MFMA f16 operand order, returned as 16384 float32
-    words (bit container for 32768 halves = 64 KB)."""
+    words (bit container for 32768 halves = 64 KB).  hi + lo reproduces w to max(2^-22 |w|, 2^-25): below
+    |w| ~ 2^-3 the `lo` half is a subnormal fp16 and the error is an absolute 2^-25.  A weight beyond
+    the fp16 range has no such split (hi would be inf): ValueError."""
     assert tuple(w.shape) == (H, H)
     g = (w.detach().float().cpu() * scale)[_ROWS_H, _COLS_H]           # [ks, bo, lane, 8] fp32
+    if not bool(torch.isfinite(g).all()) or float(g.abs().max()) > FP16_MAX:
+        raise ValueError(f"weight block with max |w| = {float(g.abs().max()):.4g} is outside the fp16 range "
+                         f"({FP16_MAX:.0f}) the split-fp16 contraction modes need; use precision='f32'")
     hi = g.to(torch.float16)                                           # round to nearest even
     lo = (g - hi.float()).to(torch.float16)
     packed = torch.stack([hi, lo], dim=2).contiguous()                 # [ks, bo, split, lane, 8]
@@ -131,9 +139,23 @@ def denoiser_tensors(sd):
     return t
 
 
-def denoiser_tensors_h(sd):
-    """Split-fp16 (hi/lo) copies of every 128x128 block, same names with an `h.` prefix."""
+def denoiser_tensors_h(sd, strict=True):
+    """Split-fp16 (hi/lo) copies of every 128x128 block, same names with an `h.` prefix.
+    strict=False (fp32-MFMA mode, where these copies are not read): a block outside the fp16 range is
+    stored as zeros and named in the returned dict's `unsplittable` list instead of raising."""
     sd = strip_module_prefix(sd)
+    bad = []
+    _strict_pack = globals()["pack_block_h"]
+
+    def pack_block_h(w, scale=1.0):  # noqa: F811  (shadows the module function inside this builder only)
+        try:
+            return _strict_pack(w, scale)
+        except ValueError:
+            if strict:
+                raise
+            bad.append(tuple(w.shape))
+            return torch.zeros(H * H, dtype=torch.float32)
+
     g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
     t = OrderedDict()
     for l in range(3):
@@ -161,6 +183,7 @@ def denoiser_tensors_h(sd):
         for c in range(4):
             t[d + f"Win{c}"] = pack_block_h(Win[128 * c:128 * c + 128, :])
             t[d + f"Wout{c}"] = pack_block_h(Wout[:, 128 * c:128 * c + 128])
+    t.unsplittable = len(bad)
     return t
 
 
@@ -231,8 +254,12 @@ DEFAULT_PRECISION = "f16x3"
 
 class DenoiserWeights:
     def __init__(self, state_dict, device, precision=DEFAULT_PRECISION):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision {precision!r}: one of {sorted(PRECISIONS)}")
         tensors = denoiser_tensors(state_dict)
-        tensors.update(denoiser_tensors_h(state_dict))
+        split = denoiser_tensors_h(state_dict, strict=precision != "f32")
+        self.splittable = split.unsplittable == 0      # False: some block does not fit fp16, fp32-MFMA mode only
+        tensors.update(split)
         self.blob = Blob(tensors, device)
         self.precision = precision
         self.self_condition = tensors["x_in_w"].shape[1] == 6
@@ -269,6 +296,8 @@ class DenoiserWeights:
         return w
 
     def set_precision(self, precision):
+        if precision != "f32" and not self.splittable:
+            raise ValueError("these weights hold a block outside the fp16 range: only precision 'f32' can run them")
         self.precision = precision
         self.struct.precision = PRECISIONS[precision]
 

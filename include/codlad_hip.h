@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 3
+#define CODLAD_ABI_VERSION 4
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -139,7 +139,22 @@ typedef struct {
     float *S;       /* [n_nodes][128]                 */
     float *PQ;      /* [4][n_nodes][128]              */
     float *hE;      /* [n_nodes] edge blocks (64 x 128) */
+    int32_t *status; /* [1] sticky status word (CODLAD_STATUS_*), may be NULL: set by the kernels, never
+                      * cleared by them; read and cleared by codlad_status_check                       */
 } codlad_workspace;
+
+/* Status bits.  NONFINITE: a denoiser output (eps | variance logits) was inf or NaN.  In the split-fp16
+ * contraction modes that is also what an operand beyond the fp16 range (|x| > 65504) ends in: its halves
+ * become hi = +-inf, lo = -+inf and every product they enter NaN, which LayerNorm spreads over the node and
+ * message passing over the sample - an overflow cannot come out as a finite number, so this one test at the
+ * end of every forward is the overflow sentinel, at no cost in the contraction loops. */
+#define CODLAD_STATUS_NONFINITE 1
+#define CODLAD_E_NONFINITE (-3)
+
+/* Synchronises `stream`, reads the status word and clears it.  Returns 0 if it was clear,
+ * CODLAD_E_NONFINITE (with codlad_last_error() text) if CODLAD_STATUS_NONFINITE was set, > 0 = hipError_t.
+ * The only entry point that waits for the device. */
+int codlad_status_check(int32_t *status, void *stream);
 
 /* Step- and member-invariant part of encoder layer 0: E1[0] = W1[:,128:256] @ h_E0 (message) and
  * E1[1] = W11[:,128:256] @ h_E0 (edge update) per structure edge, E1 [2][n_snodes] edge blocks.

@@ -60,23 +60,41 @@ def load_vae(args, device):
     return vae.to(device).eval()
 
 
+MAX_FRAMES_PER_BATCH = 96          # reference utils/dataset_module.py:220-226: batch_size = min(n_frames, 96)
+
+
+def chunk_plan(n_frames, max_frames=MAX_FRAMES_PER_BATCH):
+    """[(first frame, end frame)] of the batches one data file is cut into."""
+    bs = min(n_frames, max_frames)
+    return [(b, min(b + bs, n_frames)) for b in range(0, n_frames, bs)]
+
+
+def output_name(name, chunk, n_chunks):
+    """File stem of one batch's coordinates.  A data file of more than 96 frames is cut into several batches
+    (possibly dealt to different ranks): each gets its own, index-tagged file, so no batch overwrites another;
+    a single-batch file keeps the plain name."""
+    return name if n_chunks == 1 else f"{name}_b{chunk:05d}"
+
+
 def iter_batches(args):
-    """Yields (name, batch dict, info)."""
+    """Yields (output name, batch dict, info)."""
     if args.synthetic:
         lengths = {"PED": (46, 87, 92, 129), "PDB": (60, 120, 200), "Atlas": (39, 155, 505)}[args.data_type]
         for i, L in enumerate(lengths):
             prot = synth.make_protein(L, 1000 + i, n_frames=args.synthetic_frames,
                                       phospho=args.vae_type != "N6")
-            yield f"synthetic_L{L}", synth.make_batch(prot), prot["info"]
+            plan = chunk_plan(args.synthetic_frames)
+            for c, (a, b) in enumerate(plan):
+                yield output_name(f"synthetic_L{L}", c, len(plan)), synth.make_batch(prot, range(a, b)), prot["info"]
         return
     if not args.data_process:
         raise SystemExit("pdb/xtc loading needs mdtraj (out of scope): use --data_process --data_files ... or --synthetic")
     for path in args.data_files:
         with open(path, "rb") as f:
             testset, info = pickle.load(f)
-        bs = min(len(testset), 96)
-        for b in range(0, len(testset), bs):
-            yield os.path.basename(path), CG_collate([testset[i] for i in range(b, min(b + bs, len(testset)))]), info
+        plan = chunk_plan(len(testset))
+        for c, (a, b) in enumerate(plan):
+            yield output_name(os.path.basename(path), c, len(plan)), CG_collate([testset[i] for i in range(a, b)]), info
 
 
 def main(args):

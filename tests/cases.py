@@ -51,6 +51,50 @@ E2E_CASES = {
 }
 
 
+# Weight sets that probe the envelope of the split-fp16 contraction modes (f16x3 / f16x4): every case is a
+# full denoiser forward of the reference on the L46_B2 inputs (tools/gen_golden.py g10).
+ENVELOPE_GEOMETRY = (46, 2, 12)
+ENVELOPE_CASES = ("xavier", "blocks_1e-2", "blocks_1e-3", "small_first_1e-2", "small_first_1e-3", "large_first_1e2",
+                  "norm_edges_x30", "adaln_x8")
+_BLOCK_TAGS = (".W1.", ".W2.", ".W3.", ".W11.", ".W12.", ".W13.", ".dense.W_in.", ".dense.W_out.")
+
+
+def envelope_state_dict(name):
+    """xavier: the reference constructor's own initialisation (synth.reference_init_state_dict) with seeded non-zero
+    adaLN heads.  The others start from the default synthetic weights (WEIGHT_SEED):
+      blocks_<s>      every weight matrix of the message / edge-update / FFN MLPs scaled by s (the fp16 `lo` halves of
+                      such weights are subnormal);
+      small_first_<s> the FIRST layer of every MLP (W1, W11, dense.W_in; weight and bias) scaled by s and the second
+                      (W2, W12, dense.W_out weight) by 1/s: small weights that still carry the signal - the case a
+                      trained net with one small layer looks like; large_first_1e2: the other way round;
+      norm_edges_x30  features.norm_edges.weight x 30: edge features of magnitude ~30 enter the first contraction;
+      adaln_x8        every adaLN head x 8: large scale / shift / gate vectors."""
+    if name == "xavier":
+        return synth.reference_init_state_dict()
+    sd = synth.denoiser_state_dict(WEIGHT_SEED)
+    if name.startswith("blocks_"):
+        s = float(name.split("_")[1])
+        for k in sd:
+            if k.endswith(".weight") and any(t in k for t in _BLOCK_TAGS):
+                sd[k] = sd[k] * s
+    elif name.startswith("small_first_") or name.startswith("large_first_"):
+        s = float(name.split("_")[2])
+        for k in sd:
+            if any(t in k for t in (".W1.", ".W11.", ".dense.W_in.")):
+                sd[k] = sd[k] * s
+            elif k.endswith(".weight") and any(t in k for t in (".W2.", ".W12.", ".dense.W_out.")):
+                sd[k] = sd[k] / s
+    elif name == "norm_edges_x30":
+        sd["features.norm_edges.weight"] = sd["features.norm_edges.weight"] * 30.0
+    elif name == "adaln_x8":
+        for k in sd:
+            if "adaLN_modulation" in k:
+                sd[k] = sd[k] * 8.0
+    else:
+        raise KeyError(name)
+    return sd
+
+
 def denoiser_inputs(n_cg, n_frames, seed, t_value=None, phospho=False):
     prot = synth.make_protein(n_cg, seed, n_frames=n_frames, phospho=phospho)
     batch = synth.make_batch(prot)

@@ -16,11 +16,12 @@ WEIGHT_SEED, VAE_SEED = 1234, 4321
 
 
 class Config:
-    def __init__(self, name, lengths, n_frames, n_ensemble, vae_type, dataname, T=100, seed0=1000, device="cuda:0"):
+    def __init__(self, name, lengths, n_frames, n_ensemble, vae_type, dataname, T=100, seed0=1000, device="cuda:0",
+                 weight_seed=WEIGHT_SEED, vae_seed=VAE_SEED):
         self.name, self.T, self.device = name, T, torch.device(device)
-        self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), self.device)
+        self.den = Denoiser(synth.denoiser_state_dict(weight_seed), self.device)
         mean, std = synth.norm_stats(dataname, vae_type)
-        self.dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, VAE_SEED), self.device, mean, std)
+        self.dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, vae_seed), self.device, mean, std)
         self.tables = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T)))
         self.proteins = [synth.make_protein(L, seed0 + i, n_frames=n_frames) for i, L in enumerate(lengths)]
         # unit id -> (protein, frame, member); ids are stable across shardings

@@ -17,15 +17,7 @@ from tests import pipeline
 
 pytestmark = pytest.mark.gpu
 
-PED_LENGTHS = [46, 87, 92, 129]
-
-
-def atlas_like_lengths(n, seed=7):
-    """Synthetic stand-in for the `seqlen` column of the Atlas test list (39..505, median ~155)."""
-    r = np.random.Generator(np.random.PCG64(seed))
-    L = np.clip(np.exp(r.normal(np.log(155.0), 0.55, n)), 39, 505).astype(int)
-    L[0], L[1] = 39, 505
-    return [int(x) for x in L]
+PED_LENGTHS = list(synth.PED_LENGTHS)
 
 
 def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=()):
@@ -103,18 +95,26 @@ def test_cfg5_recon_decoder_only_full_size():
 
 
 def test_cfg3_pdb_k3_full_size():
-    """cfg 3: 64 proteins, one frame each, lengths 50-400, angle decoder (K3); all 64 on one GPU and
-    two of the eight per-GPU shards."""
-    lengths = [max(50, min(400, L)) for L in atlas_like_lengths(64, seed=11)]
-    cfg = pipeline.Config("cfg3", lengths, n_frames=1, n_ensemble=1, vae_type="K3", dataname="PDB")
+    """cfg 3: 64 proteins, one frame each, angle decoder (K3); lengths = the first 64 of the reference's Atlas test
+    list clipped to 50..400 (PDB lengths do not ship); all 64 on one GPU and two of the eight
+    per-GPU shards."""
+    c = synth.baseline_config("cfg3")
+    lengths = c["lengths"]
+    assert len(lengths) == 64 and min(lengths) >= 50 and max(lengths) <= 400
+    cfg = pipeline.Config("cfg3", lengths, n_frames=c["n_frames"], n_ensemble=c["n_ensemble"], vae_type=c["vae_type"],
+                          dataname=c["dataname"])
     check_job(cfg, list(range(64)), n_shards=8, shards_to_run=[0, 5], oracle_units=[int(np.argmin(lengths))])
 
 
 def test_cfg4_atlas_k4_one_gpu_share():
-    """cfg 4: 70 proteins (39..505 residues) x 4 frames x num_ensemble 32 = 8 960 structures over 8 GPUs:
-    the 1 120 structures LPT deals to rank 0, then that share split again."""
-    lengths = atlas_like_lengths(70)
-    cfg = pipeline.Config("cfg4", lengths, n_frames=4, n_ensemble=32, vae_type="K4", dataname="Atlas")
+    """cfg 4: the reference's Atlas test list (datasets/protein/Atlas/new_atlas_test.csv `seqlen`: 70 proteins,
+    39..505 residues, median 155; fixture tests/golden/atlas_test_seqlen.json) x 4 frames x num_ensemble 32 =
+    8 960 structures over 8 GPUs: the 1 120 structures LPT deals to rank 0, then that share split again."""
+    c = synth.baseline_config("cfg4")
+    lengths = c["lengths"]
+    assert len(lengths) == 70 and min(lengths) == 39 and max(lengths) == 505 and sorted(lengths)[35] == 155
+    cfg = pipeline.Config("cfg4", lengths, n_frames=c["n_frames"], n_ensemble=c["n_ensemble"], vae_type=c["vae_type"],
+                          dataname=c["dataname"])
     assert len(cfg.units) == 8960
     costs = [parallel.unit_cost(lengths[p]) for p, _f, _m in cfg.units]
     shards = parallel.shard_units(costs, 8)

@@ -388,10 +388,29 @@ def test_cg_graph_on_device_equals_reference_neighbour_list():
     assert torch.equal(ptr8.cpu(), r8[0]) and torch.equal(src8.cpu(), r8[1])
 
 
+def allowed_code_flips(lat_mine, lat_ref, codebook):
+    """Residues whose VQ code MAY legitimately differ between two runs whose latents differ by delta.
+    d_k(z) = |z - e_k|^2, so moving z by delta moves the margin d_2 - d_1 by exactly 2 delta.(e_1 - e_2):
+    a flip needs margin <= 2 |delta| |e_1 - e_2| (+ the fp32 rounding of the distance formula itself,
+    a few ulp of |z|^2 + |e|^2).  A factor 2 of slack on the first term; nothing else is tolerated.
+    Returns (allowed [n] bool, ref idx [n], margin [n])."""
+    z = lat_ref.reshape(-1, 3).double()
+    e = codebook.double()
+    d = (z ** 2).sum(1, keepdim=True) + (e ** 2).sum(1) - 2.0 * z @ e.t()
+    top = torch.topk(d, 2, dim=1, largest=False)
+    margin = top.values[:, 1] - top.values[:, 0]
+    e1, e2 = e[top.indices[:, 0]], e[top.indices[:, 1]]
+    delta = (lat_mine.reshape(-1, 3).double() - z).norm(dim=1)
+    bound = 2.0 * 2.0 * delta * (e1 - e2).norm(dim=1) + 8 * 2.0 ** -24 * ((z ** 2).sum(1) + (e1 ** 2).sum(1))
+    return margin <= bound, top.indices[:, 0], margin
+
+
 @pytest.mark.parametrize("name", list(cases.E2E_CASES))
 def test_end_to_end(den, sd, name):
-    """noise -> xyz on the GPU vs the reference CPU path: RMSD <= 1e-4 A wherever the VQ codes agree;
-    a code may legitimately differ only where the reference's own top-2 margin is a near-tie."""
+    """noise -> xyz on the GPU vs the reference CPU path.  A VQ code may differ from the reference's only where
+    the OBSERVED latent deviation of that residue can bridge the reference's own top-2 margin
+    (allowed_code_flips); every frame without such a flip must agree to RMSD <= 1e-4 A, and at least one frame
+    must be flip-free, so the coordinate comparison always runs."""
     L, B, seed, T, vae_type, dataname = cases.E2E_CASES[name]
     gold = np.load(cases.npz_path(f"g7_e2e_{name}"))
     prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
@@ -401,16 +420,27 @@ def test_end_to_end(den, sd, name):
     x0 = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tables(T))
     assert rel_err(x0.cpu().view(B, L, 3), gold["samples"]) < 1e-4
     mean, std = synth.norm_stats(dataname, vae_type)
-    dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED), DEV, mean, std)
+    vsd = synth.vqvae_state_dict(vae_type, dataname, cases.VAE_SEED)
+    dec = Decoder(vsd, DEV, mean, std)
     idx, zq, lat = dec.vq(x0)
-    differ = idx.cpu() != torch.from_numpy(gold["idx"])
-    assert not bool((differ & (torch.from_numpy(gold["margin"]) > 1e-2)).any())
+    lat_ref = torch.from_numpy(gold["samples"]) * std + mean                 # get_norm_feature(norm_in=False)
+    allowed, ref_idx, margin = allowed_code_flips(lat.cpu(), lat_ref, odec.codebook_of(vsd))
+    assert torch.equal(ref_idx, torch.from_numpy(gold["idx"]).reshape(-1))   # the golden's own codes, recomputed
+    differ = idx.cpu() != ref_idx
+    n_flip = int(differ.sum())
+    assert not bool((differ & ~allowed).any()), \
+        f"{int((differ & ~allowed).sum())} VQ codes differ where the latent deviation cannot explain it " \
+        f"(smallest such margin {float(margin[differ & ~allowed].min()):.3e})"
+    assert n_flip <= 2, f"{n_flip} near-tie code flips in {B * L} residues"
     ic = dec.ic_decode(zq, batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:], batch["CG_nbr_list"])
     xyz = dec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)[:, :, 1:].to(DEV),
                         ic.view(B, L, 13, 3), prot["info"])
-    if not bool(differ.any()):
-        rmsd = float(((xyz.cpu() - torch.from_numpy(gold["xyz"])) ** 2).sum(-1).mean().sqrt())
-        assert rmsd < 1e-4
+    clean = ~differ.view(B, L).any(dim=1)                                    # frames without a flipped code
+    assert bool(clean.any()), "every frame has a flipped VQ code: coordinates could not be compared"
+    d2 = ((xyz.cpu() - torch.from_numpy(gold["xyz"])) ** 2).sum(-1)          # [B, n_atoms]
+    rmsd = d2[clean].mean().sqrt()
+    assert float(rmsd) < 1e-4, float(rmsd)
+    print(f"{name}: {n_flip} near-tie code flips, {int(clean.sum())}/{B} frames compared, RMSD {float(rmsd):.2e} A")
 
 
 def test_random_ragged_jobs_against_oracle_and_between_modes(sd):

@@ -202,3 +202,40 @@ def test_edge_block_layout_helper():
     assert torch.equal(edge_rows(blocks), rows)
     flat = blocks.view(n, -1)
     assert float(flat[1, 256 * (77 // 4) + 4 * 13 + 77 % 4]) == float(rows[1, 13, 77])
+
+
+def test_split_pack_refuses_weights_outside_fp16_range():
+    """hi = f16(w) would be inf: the split-fp16 packer raises; the non-strict builder (fp32-MFMA mode) counts."""
+    from codlad_amd.weights import denoiser_tensors_h, pack_block_h
+    W = torch.zeros(128, 128)
+    W[2, 3] = 7.0e4
+    with pytest.raises(ValueError, match="fp16 range"):
+        pack_block_h(W)
+    pack_block_h(W, 0.5)                                   # 3.5e4 fits
+    sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
+    assert denoiser_tensors_h(sd).unsplittable == 0
+    sd["decoder_layers.2.dense.W_out.weight"] = sd["decoder_layers.2.dense.W_out.weight"].clone()
+    sd["decoder_layers.2.dense.W_out.weight"][0, 300] = -1.0e5
+    with pytest.raises(ValueError, match="fp16 range"):
+        denoiser_tensors_h(sd)
+    assert denoiser_tensors_h(sd, strict=False).unsplittable == 1
+
+
+def test_cli_batches_of_one_file_get_distinct_output_names():
+    """A data file of more than 96 frames is cut into several batches (reference dataset_module.py:220-226);
+    each must land in its own output file (round-1 bug: all chunks were saved under the file's name)."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("codlad_cli", os.path.join(ROOT, "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    assert cli.chunk_plan(10) == [(0, 10)] and cli.chunk_plan(96) == [(0, 96)]
+    assert cli.chunk_plan(200) == [(0, 96), (96, 192), (192, 200)]
+    assert cli.output_name("a.pkl", 0, 1) == "a.pkl"
+    args = types.SimpleNamespace(synthetic=True, data_type="PED", vae_type="N6", synthetic_frames=100)
+    names, frames = [], 0
+    for name, batch, info in cli.iter_batches(args):
+        names.append(name)
+        frames += int(batch["num_CGs"].shape[0])
+    assert len(names) == len(set(names)) == 8 and frames == 400          # 4 proteins x (96 + 4) frames
+    assert names[:2] == ["synthetic_L46_b00000", "synthetic_L46_b00001"]

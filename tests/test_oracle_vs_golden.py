@@ -197,3 +197,21 @@ def test_g9_self_conditioning(name):
     xs, traj = sampler.p_sample_loop(sd_sc, T, z, eps, cg_xyz, cg_z, m, return_traj=True, self_condition=True)
     assert rel_err(torch.stack(traj), gold["traj"]) < 2e-5
     assert rel_err(xs, gold["sample"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", list(cases.ENVELOPE_CASES))
+def test_g10_envelope_weight_sets(name):
+    """The oracle on the weight sets that probe the split-fp16 envelope, incl. the reference constructor's own
+    initialisation replayed by synth.reference_init_state_dict (gen_golden asserts it IS the constructor's)."""
+    L, B, seed = cases.ENVELOPE_GEOMETRY
+    gold = g(f"g10_envelope_{name}")
+    wsd = cases.envelope_state_dict(name)
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, m = denoiser.batch_to_dense(batch)
+    out = denoiser.forward(wsd, x, t, cg_xyz, cg_z, mask)
+    assert rel_err(out, gold["out"]) < 2e-6
+    if name == "xavier":
+        assert len(wsd) == 108 and sum(v.numel() for v in wsd.values()) == 2449974
+        z, eps = cases.loop_noise(10, B, L, seed)
+        xs = sampler.p_sample_loop(wsd, 10, z, eps, cg_xyz, cg_z, mask)
+        assert rel_err(xs, gold["sample"]) < 1e-5

@@ -1,0 +1,88 @@
+"""The envelope of the split-fp16 contraction modes (f16x3 default, f16x4), pinned on the GPU against goldens
+the reference produced for weight sets chosen to stress it (tests/cases.py ENVELOPE_CASES, tools/gen_golden.py g10):
+the reference constructor's own initialisation, uniformly small weight matrices, small / large first layers that
+still carry the signal, large edge-feature gains, large adaLN vectors.  Plus the overflow sentinel: an operand
+beyond the fp16 range must come back as an error code, never as a number."""
+import numpy as np
+import pytest
+import torch
+
+from codlad_amd import synth
+from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
+from codlad_amd.engine import Denoiser
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def job_of(den, prot, B):
+    frames = torch.from_numpy(prot["xyz_full"])[:, 1:-1]
+    z = torch.from_numpy(prot["z_full"])[1:-1]
+    st = den.prepare_structures([f for f in frames], [z for _ in frames])
+    return den.make_job(st, list(range(B)))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x4", "f32"])
+@pytest.mark.parametrize("name", list(cases.ENVELOPE_CASES))
+def test_envelope_weight_sets_against_reference(name, precision):
+    """Same tolerance as every other denoiser test (1e-5 relative to the output's max) in all three modes."""
+    L, B, seed = cases.ENVELOPE_GEOMETRY
+    gold = np.load(cases.npz_path(f"g10_envelope_{name}"))
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    den = Denoiser(cases.envelope_state_dict(name), DEV, precision=precision)
+    job = job_of(den, prot, B)
+    out = den.forward(job, x.reshape(-1, 3).to(DEV), int(t[0])).cpu().view(B, L, 6)
+    assert rel_err(out, gold["out"]) < 1e-5, (name, precision, rel_err(out, gold["out"]))
+    if name == "xavier":
+        T = 10
+        z, eps = cases.loop_noise(T, B, L, seed)
+        tb = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T)))
+        x0 = den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tb)
+        assert rel_err(x0.cpu().view(B, L, 3), gold["sample"]) < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x4"])
+def test_fp16_range_overflow_is_an_error_not_a_number(precision):
+    """Edge features of magnitude ~1e6 (features.norm_edges.weight x 1e6) are far outside the fp16 range: the
+    split modes must report it through the status word (RuntimeError from the host layer, CODLAD_E_NONFINITE
+    from codlad_status_check) in forward AND in the fused loop; the fp32-MFMA mode computes the same input
+    to a finite result; and the status word is cleared by the check, so the job is usable again."""
+    L, B, seed = cases.ENVELOPE_GEOMETRY
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
+    sd["features.norm_edges.weight"] = sd["features.norm_edges.weight"] * 1e6
+    xd = x.reshape(-1, 3).to(DEV)
+    den = Denoiser(sd, DEV, precision=precision)
+    job = job_of(den, prot, B)
+    with pytest.raises(RuntimeError, match="not finite"):
+        den.forward(job, xd, 500)
+    T = 3
+    z, eps = cases.loop_noise(T, B, L, seed)
+    tb = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T)))
+    with pytest.raises(RuntimeError, match="not finite"):
+        den.sample(job, z.reshape(-1, 3).to(DEV), eps.reshape(T, -1, 3).to(DEV), tb)
+    assert int(job.status.item()) == 0                                   # cleared by the failed check
+    out = den.forward(job, xd, 500, check=False)                         # unchecked call: NaNs come back as they are
+    assert not bool(torch.isfinite(out).all())
+    den.weights.set_precision("f32")
+    job.status.zero_()
+    out32 = den.forward(job, xd, 500)
+    assert bool(torch.isfinite(out32).all())
+
+
+def test_weights_beyond_fp16_range_are_refused_at_pack_time():
+    """A weight that does not fit the fp16 `hi` half cannot be split: packing raises instead of storing inf."""
+    sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
+    sd["encoder_layers.1.W2.weight"] = sd["encoder_layers.1.W2.weight"].clone()
+    sd["encoder_layers.1.W2.weight"][3, 5] = 7.0e4
+    with pytest.raises(ValueError, match="fp16 range"):
+        Denoiser(sd, DEV, precision="f16x3")
+    den = Denoiser(sd, DEV, precision="f32")                           # the fp32-MFMA mode takes it
+    assert den.weights.precision == "f32"

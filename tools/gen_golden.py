@@ -77,6 +77,59 @@ def save(name, **arrays):
 
 
 # ----------------------------------------------------------------------------
+def g10_envelope(ref):
+    """Weight sets that probe the split-fp16 contraction modes' envelope (tests/cases.py ENVELOPE_CASES): one
+    forward of the reference per set, plus a 10-step loop for the reference constructor's own initialisation."""
+    print("g10 precision-envelope weight sets")
+    L, B, seed = cases.ENVELOPE_GEOMETRY
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    # the replayed constructor initialisation must BE the constructor's
+    torch.manual_seed(7)
+    fresh = ref["MPNN_models"]["mpnn_diffusion"](input_size=3, unconditional=True, diffusion="diffusion",
+                                                 self_condition=False)
+    replay = synth.reference_init_state_dict(torch_seed=7)
+    own = fresh.state_dict()
+    assert list(own) == list(replay), "constructor order differs from synth._reference_module_plan"
+    for k in own:
+        if "adaLN_modulation" in k:
+            assert float(own[k].abs().max()) == 0.0          # latent_model.py:155-165
+        else:
+            assert torch.equal(own[k], replay[k]), k
+    for name in cases.ENVELOPE_CASES:
+        sd = cases.envelope_state_dict(name)
+        model = ref["MPNN_models"]["mpnn_diffusion"](input_size=3, unconditional=True, diffusion="diffusion",
+                                                     self_condition=False)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        out = model(x, t, None, mask=mask, batch=batch)
+        arrays = dict(out=out)
+        if name == "xavier":
+            T = 10
+            z, eps = cases.loop_noise(T, B, L, seed)
+            arrays["sample"] = run_loop(ref, model, T, z, eps, mask, batch)[-1]
+        save(f"g10_envelope_{name}", **arrays)
+
+
+# ----------------------------------------------------------------------------
+def g0_dataset_lengths(ref):
+    """Data fixture: the `seqlen` column of the reference's Atlas test list
+    (datasets/protein/Atlas/new_atlas_test.csv, 70 proteins, 39..505 residues), the lengths SURVEY.md 8(d)
+    names for cfg 4 (and, clipped to 50..400, for cfg 3).  Integers only."""
+    import csv
+    import json
+    print("g0 dataset lengths")
+    with open(os.path.join(ref["root"], "datasets/protein/Atlas/new_atlas_test.csv")) as f:
+        rows = list(csv.DictReader(f))
+    out = {"source": "datasets/protein/Atlas/new_atlas_test.csv, column seqlen, file order",
+           "seqlen": [int(r["seqlen"]) for r in rows]}
+    assert all(len(r["seqres"]) == int(r["seqlen"]) for r in rows)
+    path = os.path.join(REPO, "tests", "golden", "atlas_test_seqlen.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"  wrote {os.path.relpath(path, REPO)}: {len(rows)} proteins, {min(out['seqlen'])}..{max(out['seqlen'])}")
+
+
+# ----------------------------------------------------------------------------
 def g9_self_condition(ref):
     """Next row 8f-4: the --self_condition variant (reference test.py:196, 297-303): a model built with
     self_condition=True (x_in sees cat(x_self_cond, x), latent_model.py:112-116, 210-212) and a sampler
@@ -370,6 +423,7 @@ def main():
     def want(k):
         return only is None or k in only
 
+    if want("g0"): g0_dataset_lengths(ref)
     if want("g1"): g1_schedule(ref)
     if want("g2"): g2_forward(ref, model)
     if want("g3"): g3_loop(ref, model)
@@ -379,6 +433,7 @@ def main():
     if want("g7"): g7_end_to_end(ref, model)
     if want("g8"): g8_metrics(ref)
     if want("g9"): g9_self_condition(ref)
+    if want("g10"): g10_envelope(ref)
 
 
 if __name__ == "__main__":
