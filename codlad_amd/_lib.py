@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 5   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -31,11 +31,15 @@ class DecLayer(C.Structure):
 
 class EncLayerH(C.Structure):
     _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c")] + \
-               [("Win", P * 4), ("Wout", P * 4)]
+               [("Win", P * 4), ("Wout", P * 4)] + \
+               [(n, P) for n in ("b1", "b2", "b3", "b11", "b12", "b13", "b_in", "b_out")] + \
+               [(n, C.c_int) for n in ("e1", "e2", "e3", "e11", "e12", "e13", "e_in", "e_out")]
 
 
 class DecLayerH(C.Structure):
-    _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W1a", "W1v")] + [("Win", P * 4), ("Wout", P * 4)]
+    _fields_ = [(n, P) for n in ("W1e", "W2", "W3", "W1a", "W1v")] + [("Win", P * 4), ("Wout", P * 4)] + \
+               [(n, P) for n in ("TS", "b1", "b2", "b3", "b_in", "b_out")] + \
+               [(n, C.c_int) for n in ("e1", "e2", "e3", "e_in", "e_out")]
 
 
 class DenoiserWeights(C.Structure):

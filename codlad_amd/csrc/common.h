@@ -65,6 +65,20 @@ DEV void tile_add_row(Tile &t, const float *row, int h) {
         }
 }
 
+// t = t * scale + row (the residual entering a block-exponent-scaled accumulator, with its pre-scaled bias)
+DEV void tile_scale_add_row(Tile &t, float scale, const float *row, int h) {
+    const float4 *p = reinterpret_cast<const float4 *>(row);
+    const f32x2 sc = {scale, scale};
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = p[8 * bo + 2 * q + h];
+            tile_set_pair(t.b[bo], 4 * q, tile_pair(t.b[bo], 4 * q) * sc + f32x2{v.x, v.y});
+            tile_set_pair(t.b[bo], 4 * q + 2, tile_pair(t.b[bo], 4 * q + 2) * sc + f32x2{v.z, v.w});
+        }
+}
+
 DEV void tile_store_row(const Tile &t, float *row, int h) {
     float4 *p = reinterpret_cast<float4 *>(row);
 #pragma unroll
@@ -164,10 +178,15 @@ DEV void gemm128(Tile &acc, const Tile &in, const float *__restrict__ Wpacked, i
 // exactly the SUM of their separate times, so bias/GELU/LayerNorm work is never hidden behind an
 // fp32 contraction.  The f16 MFMA (32x32x16, 32 cycles for 16 k) has its own pipe and 16x the rate.
 // Both operands are split into two fp16 halves by round-to-nearest,
-//     x = hi + lo (+ eps),  hi = f16(x),  lo = f16(x - hi),  |eps| <= 2^-22 |x|
-// and the partial products hi*hi + hi*lo + lo*hi (+ lo*lo in the four-term mode, see mfma_f16) are
-// accumulated in fp32 by the MFMA (fp16 x fp16 products are exact in fp32).  Per 16 k this costs
-// 3-4 x 32 = 96-128 matrix-pipe cycles against 8 x 64 = 512 ALU cycles for the fp32 MFMA.
+//     x = hi + lo (+ eps),  hi = f16(x),  lo = f16(x - hi),  |eps| <= max(2^-22 |x|, 2^-25)
+// (below |x| ~ 2^-3 the `lo` half is a subnormal fp16 and the error is an ABSOLUTE 2^-25; beyond 65504 there
+// is no split at all: hi = inf), and the partial products hi*hi + hi*lo + lo*hi (+ lo*lo in the four-term
+// mode, see mfma_f16) are accumulated in fp32 by the MFMA (fp16 x fp16 products are exact in fp32).  Per 16 k
+// this costs 3-4 x 32 = 96-128 matrix-pipe cycles against 8 x 64 = 512 ALU cycles for the fp32 MFMA.
+// To keep both operands in the range where the bound is the relative one, every weight block is stored with a
+// power-of-two BLOCK EXPONENT chosen at pack time (weights.py) and the activations between the layers of an MLP
+// carry the accumulated exponent (gelu_consts below); the scale is taken out where it is free (a LayerNorm, a
+// constant multiply that exists anyway, a pre-scaled bias).  Range violations are caught by the status word.
 //
 // Layout: same chain as above.  k-step ks = 2*b + s consumes registers 8s..8s+7 of input block b;
 // element j of lane half h is feature 32*b + 16*s + 8*(j>>2) + 4*h + (j&3).  A packed weight block
@@ -214,8 +233,9 @@ DEV void mfma_f16(f32x16 &acc, f16x8 whi, f16x8 wlo, const SplitFrag &x) {
 // instructions ride free under one f16 MFMA, the rest of the vector work adds to the matrix time,
 // whether it is interleaved in the same wave, run as a separate phase or issued by the SIMD
 // partner; so the goal is simply the fewest VALU instructions.
+struct GeluK;
 template <int N>
-DEV void gelu_pairs(f32x2 (&x)[N]);
+DEV void gelu_pairs(f32x2 (&x)[N], const GeluK &gk);
 
 // lo = f16(x - f32(hi)) for a pair, in two instructions: v_fma_mix{lo,hi}_f16 read the fp16 half of
 // `hi` directly, form hi * -1 + x in fp32 (exact: hi is x rounded to 11 bits) and write the rounded
@@ -234,13 +254,13 @@ DEV f16x2 split_lo_pair(f16x2 hi, f32x2 x) {
 // contraction - the activation of k-step ks+1 then sits between the MFMAs of k-step ks of the
 // SAME tile (no second tile, no extra registers), where the matrix pipe hides it.
 template <bool GELU_IN>
-DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
+DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p, const GeluK &gk) {
     const f32x16 &v = in.b[ks >> 1];
     const int r = (ks & 1) * 8 + 2 * p;
     f32x2 x = {v[r], v[r + 1]};
     if (GELU_IN) {
         f32x2 t[1] = {x};
-        gelu_pairs<1>(t);
+        gelu_pairs<1>(t, gk);
         x = t[0];
     }
     const f16x2 hh = __builtin_convertvector(x, f16x2);
@@ -255,7 +275,7 @@ DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p) {
 // MFMAs; across it nothing moves, which keeps register pressure bounded (left alone, hipcc hoists
 // loads and epilogue arithmetic across the whole 128-MFMA block and spills hundreds of registers).
 template <int TERMS, int KS0, int NKS, bool GELU_IN, bool TRANSPOSED = false>
-DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
+DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk) {
     const u32x4 *w = wl + lane;
     constexpr int G0 = KS0 * 4, NG = NKS * 4;
     u32x4 ring[3][2];
@@ -266,7 +286,7 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
     }
     SplitFrag x, xn;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p);
+    for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p, gk);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int ks = KS0 + (g >> 2), bo = g & 3;
@@ -274,7 +294,7 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
             ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];
             ring[(g + 2) % 3][1] = w[((G0 + g + 2) * 2 + 1) * 64];
         }
-        if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
+        if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
         mfma_f16<TERMS, TRANSPOSED>(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
         __builtin_amdgcn_sched_barrier(0);
         if (bo == 3) x = xn;
@@ -283,8 +303,8 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
 
 // acc += W @ act(in): GELU_IN applies GELU to `in` on the fly (see split_pair)
 template <int TERMS, bool GELU_IN, bool TRANSPOSED = false>
-DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane) {
-    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED>(acc, in, wl, lane);
+DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk) {
+    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED>(acc, in, wl, lane, gk);
 }
 
 // The same k-step with the weight fragments fetched from global memory (L2-resident) through a
@@ -313,10 +333,10 @@ struct StreamedGemm {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    DEV void run(Tile &acc, const Tile &in, int lane) {
+    DEV void run(Tile &acc, const Tile &in, int lane, const GeluK &gk) {
         SplitFrag x, xn;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p);
+        for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p, gk);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int ks = KS0 + (g >> 2), bo = g & 3;
@@ -324,7 +344,7 @@ struct StreamedGemm {
                 ring[(g + DEPTH - 1) & (DEPTH - 1)][0] = weight_frag_load(rsrc, lane, (G0 + g + DEPTH - 1) * 2 + 0);
                 ring[(g + DEPTH - 1) & (DEPTH - 1)][1] = weight_frag_load(rsrc, lane, (G0 + g + DEPTH - 1) * 2 + 1);
             }
-            if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo);
+            if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
             mfma_f16<TERMS>(acc.b[bo], as_f16x8(ring[g & (DEPTH - 1)][0]), as_f16x8(ring[g & (DEPTH - 1)][1]), x);
             __builtin_amdgcn_sched_barrier(0);
             if (bo == 3) x = xn;
@@ -333,10 +353,10 @@ struct StreamedGemm {
 };
 
 template <int TERMS, int KS0, int NKS, bool GELU_IN>
-DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
+DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, const GeluK &gk) {
     StreamedGemm<TERMS, KS0, NKS, GELU_IN, 4> g;
     g.start(Wpacked, lane);
-    g.run(acc, in, lane);
+    g.run(acc, in, lane, gk);
 }
 
 // GELU(x) = x Phi(x) = max(x, 0) - |x| * (erfc(|x|/sqrt 2) / 2), branch-free:
@@ -371,15 +391,44 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane) {
 #else
 #error "CODLAD_GELU_DEGREE must be 5, 6 or 8"
 #endif
-DEV float gelu_erf(float x) {
-#ifdef CODLAD_EXACT_ERF
-    return (0.5f * x) * (1.0f + erff(x * 0.70710678118654752440f));
-#else
+// GELU on a value that carries a power-of-two scale (block exponents of the split-fp16 modes, see
+// weights.py / DESIGN.md): for x' = 2^E x the functions below return 2^E GELU(x), bit for bit the scaled
+// result of the unscaled evaluation, at the same instruction count: with s' = 2^E s the Horner steps become
+// p' <- p' s' + c_k 2^(-E (D+1-k)) (every intermediate an exact power-of-two multiple of the unscaled one),
+// the exponent argument s' p' - 1 is the unscaled one, and max(x', 0) - |x'| e = 2^E (max(x, 0) - |x| e).
+// The constants are per-launch values (kernel arguments -> SGPRs); E = 0 gives the plain coefficients.
+struct GeluK {
+    float c[CODLAD_GELU_DEGREE + 1];
+    float clamp;       // CODLAD_GELU_CLAMP * 2^E
+    float up, down;    // 2^E, 2^-E (exact-erf A/B build only)
+};
+
+__host__ __device__ inline float pow2i(int e) {     // 2^e, |e| <= 126
+    union { unsigned u; float f; } v;
+    v.u = (unsigned)(127 + e) << 23;
+    return v.f;
+}
+
+__host__ __device__ inline GeluK gelu_consts(int E) {
     constexpr float cf[CODLAD_GELU_DEGREE + 1] = CODLAD_GELU_COEFFS;
-    const float s = fminf(fabsf(x), CODLAD_GELU_CLAMP);
-    float p = cf[0];
+    GeluK k;
+    for (int i = 0; i <= CODLAD_GELU_DEGREE; ++i) k.c[i] = cf[i] * pow2i(-E * (CODLAD_GELU_DEGREE + 1 - i));
+    k.clamp = CODLAD_GELU_CLAMP * pow2i(E);
+    k.up = pow2i(E);
+    k.down = pow2i(-E);
+    return k;
+}
+constexpr int CODLAD_MAX_CHAIN_EXP = 16;   // |E| bound of a GELU input: c_0 2^(-6E) stays a normal fp32
+
+DEV float gelu_erf(float x, const GeluK &gk) {
+#ifdef CODLAD_EXACT_ERF
+    const float u = x * gk.down;
+    return ((0.5f * u) * (1.0f + erff(u * 0.70710678118654752440f))) * gk.up;
+#else
+    const float s = fminf(fabsf(x), gk.clamp);
+    float p = gk.c[0];
 #pragma unroll
-    for (int k = 1; k <= CODLAD_GELU_DEGREE; ++k) p = fmaf(p, s, cf[k]);
+    for (int k = 1; k <= CODLAD_GELU_DEGREE; ++k) p = fmaf(p, s, gk.c[k]);
     const float e = __builtin_amdgcn_exp2f(fmaf(p, s, -1.0f));
     return fmaf(-e, fabsf(x), fmaxf(x, 0.0f));
 #endif
@@ -408,20 +457,26 @@ DEV float half_wave_sum(float v) {
 // side so that the dependent steps of one pair are separated by those of the others (a
 // v_pk_fma_f32 that consumes the previous one's result otherwise costs an s_nop).
 template <int N>
-DEV void gelu_pairs(f32x2 (&x)[N]) {
-    constexpr float cf[CODLAD_GELU_DEGREE + 1] = CODLAD_GELU_COEFFS;
+DEV void gelu_pairs(f32x2 (&x)[N], const GeluK &gk) {
+#ifdef CODLAD_EXACT_ERF
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x[i].x = gelu_erf(x[i].x, gk);
+        x[i].y = gelu_erf(x[i].y, gk);
+    }
+#else
     f32x2 t[N], p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        t[i].x = fminf(fabsf(x[i].x), CODLAD_GELU_CLAMP);
-        t[i].y = fminf(fabsf(x[i].y), CODLAD_GELU_CLAMP);
+        t[i].x = fminf(fabsf(x[i].x), gk.clamp);
+        t[i].y = fminf(fabsf(x[i].y), gk.clamp);
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = t[i] * cf[0] + cf[1];
+    for (int i = 0; i < N; ++i) p[i] = t[i] * gk.c[0] + gk.c[1];
 #pragma unroll
     for (int k = 2; k <= CODLAD_GELU_DEGREE; ++k)
 #pragma unroll
-        for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + cf[k];
+        for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + gk.c[k];
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + -1.0f;     // s g(s) - 1
 #pragma unroll
@@ -430,15 +485,10 @@ DEV void gelu_pairs(f32x2 (&x)[N]) {
         x[i].x = fmaf(-ex, fabsf(x[i].x), fmaxf(x[i].x, 0.0f));
         x[i].y = fmaf(-ey, fabsf(x[i].y), fmaxf(x[i].y, 0.0f));
     }
+#endif
 }
 
-DEV void tile_gelu(Tile &t) {
-#ifdef CODLAD_EXACT_ERF
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t.b[bo][r] = gelu_erf(t.b[bo][r]);
-#else
+DEV void tile_gelu(Tile &t, const GeluK &gk) {
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
@@ -446,14 +496,13 @@ DEV void tile_gelu(Tile &t) {
             f32x2 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = f32x2{t.b[bo][r + 2 * i], t.b[bo][r + 2 * i + 1]};
-            gelu_pairs<4>(v);
+            gelu_pairs<4>(v, gk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 t.b[bo][r + 2 * i] = v[i].x;
                 t.b[bo][r + 2 * i + 1] = v[i].y;
             }
         }
-#endif
 }
 
 // sum over the lane's own 64 features plus the partner half's 64 -> all 128 features of a column

@@ -30,6 +30,12 @@ struct EdgeArgs {
     const float *mods3;    // edge update: shift3, scale3, gate3 (3 x 128)
     float *S;              // message: [n_nodes][128]
     int n_nodes;
+    // split-fp16 modes (block exponents, common.h): GELU constants for the input of layer 2 (scale 2^E1) and of
+    // layer 3 / the message epilogue (2^(E1+E2)); edge update: the residual enters layer 3's accumulator as
+    // h_E * res_scale (= 2^(E1+E2+E3)) and the LayerNorm runs with eps * res_scale^2 (exactly equivalent).
+    // b2 / b3 point at biases pre-scaled to match.
+    GeluK gelu_a, gelu_b;
+    float res_scale, ln_eps;
 };
 
 template <bool EDGE_UPDATE>
@@ -59,10 +65,11 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
             tile_load_edge(x, rows, colc, h);
             gemm128(acc, x, a.W1, lane);
         }
-        tile_gelu(acc);
+        const GeluK gk = gelu_consts(0);
+        tile_gelu(acc, gk);
         tile_load_row(x, a.b2, h);
         gemm128(x, acc, a.W2, lane);
-        tile_gelu(x);
+        tile_gelu(x, gk);
 
         if (!EDGE_UPDATE) {
             // S[n] = sum over the valid columns; each half reduces its 32 lanes, the second
@@ -216,16 +223,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
             if (HOISTED) {
                 tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
             } else {
-                gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane);   // layer 1, resident k-steps
-                tail1.run(acc, x, lane);                                    // layer 1, streamed k-steps
+                gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps
+                tail1.run(acc, x, lane, a.gelu_a);                                    // layer 1, streamed k-steps
             }
             tile_load_row(t2, c_b2, h);
-            gemm128_h_lds<TERMS, true>(t2, acc, w2, lane);             // layer 2 on GELU(layer 1)
-            // layer 3 accumulates onto h_E + b13: the input tile stays in registers for the
-            // residual instead of being fetched from HBM a second time
-            tile_add_row(x, c_b3, h);
-            gemm128_h_lds<TERMS, true>(x, t2, w3, lane);               // layer 3 on GELU(layer 2)
-            tile_layernorm_affine(x, 1e-6f, c_modA, c_modB, h);
+            gemm128_h_lds<TERMS, true>(t2, acc, w2, lane, a.gelu_a);   // layer 2 on GELU(layer 1)
+            // layer 3 accumulates onto (h_E + b13) * 2^E: the input tile stays in registers for the
+            // residual instead of being fetched from HBM a second time (c_b3 holds b13 * 2^E)
+            tile_scale_add_row(x, a.res_scale, c_b3, h);
+            gemm128_h_lds<TERMS, true>(x, t2, w3, lane, a.gelu_b);     // layer 3 on GELU(layer 2)
+            tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);
             if (valid) tile_store_edge(x, out_rows, col, h);
         }
     }
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
 #pragma unroll
             for (int bo = 0; bo < 4; ++bo) acc.b[bo] += x.b[bo];
         } else {
-            gemm128_h_lds<TERMS, false>(acc, x, w1, lane);      // layer 1
+            gemm128_h_lds<TERMS, false>(acc, x, w1, lane, a.gelu_a);      // layer 1
         }
         if (first_half && next_node) {                   // next node's neighbour list and P row
             nsrc = __builtin_amdgcn_readfirstlane(ninfo.x);
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) t2.b[bo][r] = bv;
         }
-        gemm128_h_lds<TERMS, true, true>(t2, acc, w2, lane);    // layer 2 on GELU(layer 1), output transposed
+        gemm128_h_lds<TERMS, true, true>(t2, acc, w2, lane, a.gelu_a);    // layer 2 on GELU(layer 1), output transposed
         {   // edge rows and Q rows of the next tile, in flight during the epilogue
             const int pn = next_half ? n : (next_node ? n2 : n), ps = next_half ? src : nsrc;
             const int pe = next_half ? (32 + c < K ? 32 + c : 0) : (c < nK ? c : 0);
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
             tile_load_row(acc, a.Q + (size_t)pq * HD, h);
             __builtin_amdgcn_sched_barrier(0);
         }
-        tile_gelu(t2);
+        tile_gelu(t2, a.gelu_b);
         const int cnt = K - 32 * half;                   // valid edges of this tile (wave-uniform)
         if (cnt >= 32) {
 #pragma unroll
@@ -391,6 +398,12 @@ struct NodeArgs {
     int venc_is_self;                  // h_Venc == new h_V (first decoder layer's Q)
     // precision 1, 2: split-fp16 copies of the blocks in execution order: [W3, Win0, Wout0, .., Wout3,] proj0..
     const void *blk_h[13];
+    // block exponents (split-fp16 modes; all 1 / plain in the fp32 mode): S arrives scaled by the message MLP's
+    // accumulated exponent and is contracted as S * s_scale (= 2^-(E1+E2) / 64); the W3 term comes out as
+    // t * 2^e3 / 64 and is added as (t * t_scale) / 30 (t_scale = 64 * 2^-e3); the FFN output carries
+    // 2^(e_in+e_out) and is added as t * ffn_scale.  b3, b_in, b_out, proj_b, TS are pre-scaled to match.
+    float s_scale, t_scale, ffn_scale;
+    GeluK gelu_ffn;
 };
 
 template <bool MODE_UPD>
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(64, 1) void node_kernel(NodeArgs a) {
         for (int ch = 0; ch < 4; ++ch) {
             tile_load_row(s, a.b_in + ch * HD, h);
             gemm128(s, v, a.Win[ch], lane);
-            tile_gelu(s);
+            tile_gelu(s, gelu_consts(0));
             gemm128(t, s, a.Wout[ch], lane);
         }
 #pragma unroll
@@ -524,8 +537,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
         const bool more = cur + 1 < n_blk;
         if (more) fetch(cur + 1);
         const u32x4 *w = wl + (cur & 1) * LDS_BLOCK_U4;
-        if (gelu_in) gemm128_h_lds<TERMS, true>(acc, in, w, lane);
-        else gemm128_h_lds<TERMS, false>(acc, in, w, lane);
+        if (gelu_in) gemm128_h_lds<TERMS, true>(acc, in, w, lane, a.gelu_ffn);
+        else gemm128_h_lds<TERMS, false>(acc, in, w, lane, a.gelu_ffn);
         if (more) landed();
         __syncthreads();
         ++cur;
@@ -574,19 +587,20 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
         tile_load_row(t, a.b3, h);
         // S is a sum over up to 64 neighbours and the only operand of the path that is not
         // normalised: contract W3 with S/64 (exact power-of-two scaling, undone below) so that the
-        // fp16 halves keep 64x more headroom before 65504.
+        // fp16 halves keep 64x more headroom before 65504.  The same two multiplies take the block
+        // exponents out: S arrives as 2^(E1+E2) S, the W3 block as 2^e3 W3 (a.b3 = 2^e3 b3).
         const float kf = (float)info.z * 0.015625f;
 #pragma unroll
         for (int bo = 0; bo < 4; ++bo) {
             t.b[bo] *= kf;
-            s.b[bo] *= 0.015625f;
+            s.b[bo] *= a.s_scale;
         }
         apply(t, s, false);                                                   // W3 @ S
         tile_load_row(v, a.hV + (size_t)nc * HD, h);
 #pragma unroll
         for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v.b[bo][r] += (t.b[bo][r] * 64.0f) / 30.0f;
+            for (int r = 0; r < 16; ++r) v.b[bo][r] += (t.b[bo][r] * a.t_scale) / 30.0f;
         tile_layernorm_affine(v, 1e-6f, modAB, modAB + HD, h);
         tile_load_row(t, a.b_out, h);
 #pragma unroll 1
@@ -596,7 +610,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
             apply(t, s, true);                                                // W_out chunk on GELU(hidden)
         }
 #pragma unroll
-        for (int bo = 0; bo < 4; ++bo) v.b[bo] += t.b[bo];
+        for (int bo = 0; bo < 4; ++bo) v.b[bo] += t.b[bo] * a.ffn_scale;      // exact: power-of-two scale, then the add
         tile_layernorm_affine(v, 1e-6f, modAB + 2 * HD, modAB + 3 * HD, h);
     }
     if (valid) {
@@ -675,11 +689,16 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] += a.out_b[k];
     if (a.status) {
-        // inf / NaN by exponent bits: this file is built with -fno-honor-nans, which lets the compiler
-        // fold a floating-point self-comparison away; an integer test it cannot
+        // inf / NaN by exponent bits.  This file is built with -fno-honor-nans: the compiler folds x != x away and
+        // even turns the bit test on a float's bits into |x| == inf (false for NaN), so the bits are laundered
+        // through an empty asm and tested as the integers they then are.
         bool bad = false;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) bad |= (__float_as_uint(o[k]) & 0x7f800000u) == 0x7f800000u;
+        for (int k = 0; k < 6; ++k) {
+            unsigned u = __float_as_uint(o[k]);
+            asm volatile("" : "+v"(u));
+            bad |= (u & 0x7f800000u) == 0x7f800000u;
+        }
         if (bad) atomicOr(a.status, CODLAD_STATUS_NONFINITE);
     }
     if (a.logits) {
@@ -857,6 +876,30 @@ static void launch_node(bool upd, const NodeArgs &na, int precision, hipStream_t
     else hipLaunchKernelGGL(node_kernel<false>, grid, block, 0, st, na);
 }
 
+// Everything an edge / node launch needs that depends on the contraction mode: in the split-fp16 modes the
+// biases are the pre-scaled copies and the block exponents become scale constants (include/codlad_hip.h).
+static void set_msg_scales(EdgeArgs &ea, bool split, const float *b2, const float *b2h, int e1, int e2) {
+    ea.b2 = split ? b2h : b2;
+    ea.gelu_a = gelu_consts(split ? e1 : 0);
+    ea.gelu_b = gelu_consts(split ? e1 + e2 : 0);
+    ea.res_scale = 1.0f; ea.ln_eps = 1e-6f;
+}
+static void set_upd_scales(EdgeArgs &eu, bool split, const codlad_enc_layer &L, const codlad_enc_layer_h &Lh) {
+    eu.b2 = split ? Lh.b12 : L.b12; eu.b3 = split ? Lh.b13 : L.b13;
+    const int E2 = split ? Lh.e11 + Lh.e12 : 0, E3 = split ? E2 + Lh.e13 : 0;
+    eu.gelu_a = gelu_consts(split ? Lh.e11 : 0);
+    eu.gelu_b = gelu_consts(E2);
+    eu.res_scale = pow2i(E3);
+    eu.ln_eps = 1e-6f * pow2i(2 * E3);
+}
+// node update that follows a message kernel with accumulated exponent e_msg = e1 + e2
+static void set_node_scales(NodeArgs &na, bool split, int e_msg, int e3, int e_in, int e_out) {
+    na.s_scale = 0.015625f * pow2i(split ? -e_msg : 0);
+    na.t_scale = 64.0f * pow2i(split ? -e3 : 0);
+    na.ffn_scale = pow2i(split ? -(e_in + e_out) : 0);
+    na.gelu_ffn = gelu_consts(split ? e_in : 0);
+}
+
 // One denoiser forward up to (not including) the final layer: leaves h_V in ws->hV.
 static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                             int n_nodes, const int32_t *E_idx, const float *h_E0, const float *E1,
@@ -865,6 +908,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
     const int4 *ni = reinterpret_cast<const int4 *>(node_info);
     const size_t NS = (size_t)n_nodes * HD;
     float *PQ0 = ws->PQ, *PQ1 = ws->PQ + NS, *PQ2 = ws->PQ + 2 * NS, *PQ3 = ws->PQ + 3 * NS;
+    const bool split = w->precision != 0;
 
     // h_V = x_in(x); P/Q for encoder layer 0's message
     {
@@ -873,42 +917,45 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         na.x = x; na.x_in_w = w->x_in_w; na.x_in_b = w->x_in_b; na.hV = ws->hV;
         na.x_sc = x_self_cond; na.in_dim = w->self_condition ? 6 : 3;
         na.n_proj = 2;
-        na.proj_w[0] = w->enc[0].W1a; na.proj_b[0] = w->enc[0].b1; na.proj_out[0] = PQ0;
+        na.proj_w[0] = w->enc[0].W1a; na.proj_b[0] = split ? w->enc_h[0].b1 : w->enc[0].b1; na.proj_out[0] = PQ0;
         na.proj_w[1] = w->enc[0].W1c; na.proj_b[1] = nullptr;      na.proj_out[1] = PQ1;
         na.blk_h[0] = w->enc_h[0].W1a; na.blk_h[1] = w->enc_h[0].W1c;
+        set_node_scales(na, split, 0, 0, 0, 0);
         launch_node(false, na, w->precision, st);
     }
     for (int l = 0; l < 3; ++l) {
         const codlad_enc_layer &L = w->enc[l];
+        const codlad_enc_layer_h &Lh = w->enc_h[l];
         const float *m = mods_t + mods_offset(l);
         EdgeArgs ea = {};
         ea.node_info = ni; ea.E_idx = E_idx; ea.n_nodes = n_nodes;
         ea.hE_in = l == 0 ? h_E0 : ws->hE; ea.in_by_src = l == 0;
-        ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
-        ea.W1h = w->enc_h[l].W1e; ea.W2h = w->enc_h[l].W2;
+        ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.S = ws->S;
+        ea.W1h = Lh.W1e; ea.W2h = Lh.W2;
+        set_msg_scales(ea, split, L.b2, Lh.b2, Lh.e1, Lh.e2);
         if (l == 0 && E1) ea.E1 = E1;
         launch_edge(false, ea, w->precision, st);
 
         NodeArgs na = {};
         na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
-        na.W3 = L.W3; na.b3 = L.b3; na.mods = m;
+        na.W3 = L.W3; na.b3 = split ? Lh.b3 : L.b3; na.mods = m;
         for (int c = 0; c < 4; ++c) { na.Win[c] = L.Win[c]; na.Wout[c] = L.Wout[c]; }
-        na.b_in = L.b_in; na.b_out = L.b_out;
+        na.b_in = split ? Lh.b_in : L.b_in; na.b_out = split ? Lh.b_out : L.b_out;
+        set_node_scales(na, split, Lh.e1 + Lh.e2, Lh.e3, Lh.e_in, Lh.e_out);
         na.n_proj = 4;
-        na.proj_w[0] = L.W11a; na.proj_b[0] = L.b11;   na.proj_out[0] = PQ2;   // edge update P
-        na.proj_w[1] = L.W11c; na.proj_b[1] = nullptr; na.proj_out[1] = PQ3;   // edge update Q
+        na.proj_w[0] = L.W11a; na.proj_b[0] = split ? Lh.b11 : L.b11; na.proj_out[0] = PQ2;   // edge update P
+        na.proj_w[1] = L.W11c; na.proj_b[1] = nullptr;                 na.proj_out[1] = PQ3;   // edge update Q
         if (l < 2) {
-            na.proj_w[2] = w->enc[l + 1].W1a; na.proj_b[2] = w->enc[l + 1].b1; na.proj_out[2] = PQ0;
+            na.proj_w[2] = w->enc[l + 1].W1a; na.proj_b[2] = split ? w->enc_h[l + 1].b1 : w->enc[l + 1].b1; na.proj_out[2] = PQ0;
             na.proj_w[3] = w->enc[l + 1].W1c; na.proj_b[3] = nullptr;          na.proj_out[3] = PQ1;
         } else {
             // first decoder layer: h_Venc := this h_V, so its neighbour term sees 2*h_V
-            na.proj_w[2] = w->dec[0].W1a; na.proj_b[2] = w->dec[0].b1; na.proj_out[2] = PQ0;
+            na.proj_w[2] = w->dec[0].W1a; na.proj_b[2] = split ? w->dec_h[0].b1 : w->dec[0].b1; na.proj_out[2] = PQ0;
             na.proj_w[3] = w->dec[0].W1v; na.proj_b[3] = nullptr;      na.proj_out[3] = PQ1;
-            na.proj_flags[3] = 3; na.TS = w->dec[0].TS;
+            na.proj_flags[3] = 3; na.TS = split ? w->dec_h[0].TS : w->dec[0].TS;
             na.hVenc_out = ws->hVenc; na.venc_is_self = 1;
         }
         {
-            const codlad_enc_layer_h &Lh = w->enc_h[l];
             int k = 0;
             na.blk_h[k++] = Lh.W3;
             for (int c = 0; c < 4; ++c) { na.blk_h[k++] = Lh.Win[c]; na.blk_h[k++] = Lh.Wout[c]; }
@@ -922,33 +969,36 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         eu.node_info = ni; eu.E_idx = E_idx; eu.n_nodes = n_nodes;
         eu.hE_in = l == 0 ? h_E0 : ws->hE; eu.in_by_src = l == 0; eu.hE_out = ws->hE;
         eu.P = PQ2; eu.Q = PQ3; eu.W1 = L.W11e; eu.W2 = L.W12; eu.W3 = L.W13;
-        eu.b2 = L.b12; eu.b3 = L.b13; eu.mods3 = m + 6 * HD;
-        eu.W1h = w->enc_h[l].W11e; eu.W2h = w->enc_h[l].W12; eu.W3h = w->enc_h[l].W13;
+        eu.mods3 = m + 6 * HD;
+        eu.W1h = Lh.W11e; eu.W2h = Lh.W12; eu.W3h = Lh.W13;
+        set_upd_scales(eu, split, L, Lh);
         if (l == 0 && E1) eu.E1 = E1 + n_snodes * 64 * HD;
         launch_edge(true, eu, w->precision, st);
     }
     for (int l = 0; l < 3; ++l) {
         const codlad_dec_layer &L = w->dec[l];
+        const codlad_dec_layer_h &Lh = w->dec_h[l];
         EdgeArgs ea = {};
         ea.node_info = ni; ea.E_idx = E_idx; ea.n_nodes = n_nodes;
         ea.hE_in = ws->hE; ea.in_by_src = 0;
-        ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
-        ea.W1h = w->dec_h[l].W1e; ea.W2h = w->dec_h[l].W2;
+        ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.S = ws->S;
+        ea.W1h = Lh.W1e; ea.W2h = Lh.W2;
+        set_msg_scales(ea, split, L.b2, Lh.b2, Lh.e1, Lh.e2);
         launch_edge(false, ea, w->precision, st);
 
         NodeArgs na = {};
         na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
-        na.W3 = L.W3; na.b3 = L.b3; na.mods = mods_t + mods_offset(3 + l);
+        na.W3 = L.W3; na.b3 = split ? Lh.b3 : L.b3; na.mods = mods_t + mods_offset(3 + l);
         for (int c = 0; c < 4; ++c) { na.Win[c] = L.Win[c]; na.Wout[c] = L.Wout[c]; }
-        na.b_in = L.b_in; na.b_out = L.b_out;
+        na.b_in = split ? Lh.b_in : L.b_in; na.b_out = split ? Lh.b_out : L.b_out;
+        set_node_scales(na, split, Lh.e1 + Lh.e2, Lh.e3, Lh.e_in, Lh.e_out);
         if (l < 2) {
             na.n_proj = 2;
-            na.proj_w[0] = w->dec[l + 1].W1a; na.proj_b[0] = w->dec[l + 1].b1; na.proj_out[0] = PQ0;
+            na.proj_w[0] = w->dec[l + 1].W1a; na.proj_b[0] = split ? w->dec_h[l + 1].b1 : w->dec[l + 1].b1; na.proj_out[0] = PQ0;
             na.proj_w[1] = w->dec[l + 1].W1v; na.proj_b[1] = nullptr;          na.proj_out[1] = PQ1;
-            na.proj_flags[1] = 3; na.TS = w->dec[l + 1].TS; na.hVenc_in = ws->hVenc;
+            na.proj_flags[1] = 3; na.TS = split ? w->dec_h[l + 1].TS : w->dec[l + 1].TS; na.hVenc_in = ws->hVenc;
         }
         {
-            const codlad_dec_layer_h &Lh = w->dec_h[l];
             int k = 0;
             na.blk_h[k++] = Lh.W3;
             for (int c = 0; c < 4; ++c) { na.blk_h[k++] = Lh.Win[c]; na.blk_h[k++] = Lh.Wout[c]; }
@@ -1075,7 +1125,7 @@ __global__ __launch_bounds__(256, 1) void layer0_kernel(Layer0Args a) {
         for (int which = 0; which < 2; ++which) {
             Tile acc;
             tile_zero(acc);
-            if constexpr (TERMS != 0) gemm_h_glb<TERMS, 0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane);
+            if constexpr (TERMS != 0) gemm_h_glb<TERMS, 0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane, gelu_consts(0));
             else gemm128(acc, x, which ? a.W_upd : a.W_msg, lane);
             if (valid) tile_store_edge(acc, a.E1 + ((size_t)which * a.n_snodes + m) * EDGE_BLOCK, col, h);
         }
@@ -1111,14 +1161,18 @@ extern "C" int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const 
     ea.node_info = reinterpret_cast<const int4 *>(node_info); ea.E_idx = E_idx; ea.n_nodes = n_nodes;
     // layer 0 reads the shared structure-edge state, layer 1 the per-sample edge state (in place)
     ea.hE_in = layer == 0 ? h_E0 : ws->hE; ea.in_by_src = layer == 0;
+    const codlad_enc_layer_h &Lh = w->enc_h[layer];
+    const bool split = w->precision != 0;
     if (which == 0) {
-        ea.P = ws->PQ; ea.Q = ws->PQ + NS; ea.W1 = L.W1e; ea.W2 = L.W2; ea.b2 = L.b2; ea.S = ws->S;
-        ea.W1h = w->enc_h[layer].W1e; ea.W2h = w->enc_h[layer].W2;
+        ea.P = ws->PQ; ea.Q = ws->PQ + NS; ea.W1 = L.W1e; ea.W2 = L.W2; ea.S = ws->S;
+        ea.W1h = Lh.W1e; ea.W2h = Lh.W2;
+        set_msg_scales(ea, split, L.b2, Lh.b2, Lh.e1, Lh.e2);
     } else {
         ea.hE_out = ws->hE; ea.P = ws->PQ + 2 * NS; ea.Q = ws->PQ + 3 * NS;
-        ea.W1 = L.W11e; ea.W2 = L.W12; ea.W3 = L.W13; ea.b2 = L.b12; ea.b3 = L.b13;
+        ea.W1 = L.W11e; ea.W2 = L.W12; ea.W3 = L.W13;
         ea.mods3 = mods_t + 6 * HD;
-        ea.W1h = w->enc_h[layer].W11e; ea.W2h = w->enc_h[layer].W12; ea.W3h = w->enc_h[layer].W13;
+        ea.W1h = Lh.W11e; ea.W2h = Lh.W12; ea.W3h = Lh.W13;
+        set_upd_scales(ea, split, L, Lh);
     }
     launch_edge(which == 1, ea, w->precision, (hipStream_t)stream);
     return codlad_check_launch("codlad_bench_edge_launch");
@@ -1136,7 +1190,7 @@ __global__ __launch_bounds__(64) void selftest_kernel(const float *Wp, const flo
     tile_load_row(in, X + (size_t)rc * HD, h);
     tile_load_row(acc, bias, h);
     gemm128(acc, in, Wp, lane);
-    if (act) tile_gelu(acc);
+    if (act) tile_gelu(acc, gelu_consts(0));
     if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
 }
 
@@ -1149,8 +1203,8 @@ __global__ __launch_bounds__(64) void selftest_h_kernel(const void *Wh, const fl
     Tile in, acc;
     tile_load_row(in, X + (size_t)rc * HD, h);
     tile_load_row(acc, bias, h);
-    if (act) gemm_h_glb<TERMS, 0, 8, true>(acc, in, Wh, lane);    // Y = W gelu(X) + b
-    else gemm_h_glb<TERMS, 0, 8, false>(acc, in, Wh, lane);       // Y = W X + b
+    if (act) gemm_h_glb<TERMS, 0, 8, true>(acc, in, Wh, lane, gelu_consts(0));    // Y = W gelu(X) + b
+    else gemm_h_glb<TERMS, 0, 8, false>(acc, in, Wh, lane, gelu_consts(0));       // Y = W X + b
     if (row < n_rows) tile_store_row(acc, Y + (size_t)row * HD, h);
 }
 

@@ -49,6 +49,7 @@ class Structures:
         self.E_idx = None
         self.h_E0 = None
         self.E1 = None        # [2] x edge blocks: hoisted layer-0 edge terms (optional)
+        self.features_tag = None   # contraction mode + block exponents E1 was computed with (Denoiser.features_tag)
 
 
 class Job:
@@ -93,12 +94,12 @@ class Job:
 class Denoiser:
     """mpnn_diffusion on the GPU."""
 
-    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION):
+    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION, block_exponents=True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")
         self.lib = _lib.lib()
-        self.weights = DenoiserWeights(state_dict, self.device, precision)
+        self.weights = DenoiserWeights(state_dict, self.device, precision, block_exponents=block_exponents)
         self._mods_cache = {}
 
     # -- step-invariant part -------------------------------------------------------------------
@@ -127,7 +128,20 @@ class Denoiser:
                                                    st.n_snodes, _lib.ptr(st.h_E0), _lib.ptr(st.E1),
                                                    _lib.stream_ptr(self.device))
             _lib.check(rc, "codlad_layer0_edge_terms")
+        st.features_tag = self.features_tag()
         return st
+
+    def features_tag(self):
+        """What the hoisted layer-0 terms E1 depend on besides the structure: in the split-fp16 modes they carry
+        encoder layer 0's block exponents (E1[0] = 2^e1 W1e h_E0, E1[1] = 2^e11 W11e h_E0), in the fp32 mode none."""
+        if self.weights.precision == "f32":
+            return ("f32",)
+        ex = self.weights.exponents["enc0"]
+        return ("split", self.weights.precision, ex["e1"], ex["e11"])
+
+    def _fresh_features(self, st):
+        if st.features_tag != self.features_tag():     # e.g. set_precision() after the structures were prepared
+            self.compute_features(st)
 
     def prepare_structures(self, xyz_list, z_list, hoist_layer0=True):
         return self.compute_features(self.new_structures(xyz_list, z_list, hoist_layer0))
@@ -177,6 +191,7 @@ class Denoiser:
         mods = self.step_mods([t_value])
         out = torch.empty(job.n_nodes, 6, dtype=torch.float32, device=self.device)
         st = job.structures
+        self._fresh_features(st)
         rc = self.lib.codlad_denoiser_forward(C.byref(self.weights.struct), _lib.ptr(job.node_info),
                                               job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),
                                               _lib.ptr(st.E1), st.n_snodes, _lib.ptr(x), _lib.ptr(x_self_cond),
@@ -200,6 +215,7 @@ class Denoiser:
         mods = self.step_mods(tables.timestep_map)
         coef = torch.from_numpy(tables.step_coefficients()).to(self.device)
         st = job.structures
+        self._fresh_features(st)
         x_start = torch.empty_like(x) if self.self_condition else None   # pred_xstart, step to step
         rc = self.lib.codlad_sample_loop(C.byref(self.weights.struct), _lib.ptr(job.node_info),
                                          job.n_nodes, _lib.ptr(st.E_idx), _lib.ptr(st.h_E0),

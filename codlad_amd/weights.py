@@ -54,13 +54,16 @@ _ROWS_H, _COLS_H = _pack_index_h()
 
 
 FP16_MAX = 65504.0
+MAX_CHAIN_EXP = 16          # CODLAD_MAX_CHAIN_EXP of csrc/common.h: |accumulated exponent| at a GELU input
+MAX_RANGE_LOSS = 6          # a matrix whose largest weight forces its exponent this far below the wanted one is refused
 
 
 def pack_block_h(w, scale=1.0):
     """[128,128] block -> hi/lo fp16 split in MFMA f16 operand order, returned as 16384 float32
     words (bit container for 32768 halves = 64 KB).  hi + lo reproduces w to max(2^-22 |w|, 2^-25): below
-    |w| ~ 2^-3 the `lo` half is a subnormal fp16 and the error is an absolute 2^-25.  A weight beyond
-    the fp16 range has no such split (hi would be inf): ValueError."""
+    |w| ~ 2^-3 the `lo` half is a subnormal fp16 and the error is an absolute 2^-25 (which is why the blocks
+    of a model are packed with block exponents, `block_exponent`).  A weight beyond the fp16 range has no
+    such split (hi would be inf): ValueError."""
     assert tuple(w.shape) == (H, H)
     g = (w.detach().float().cpu() * scale)[_ROWS_H, _COLS_H]           # [ks, bo, lane, 8] fp32
     if not bool(torch.isfinite(g).all()) or float(g.abs().max()) > FP16_MAX:
@@ -70,6 +73,47 @@ def pack_block_h(w, scale=1.0):
     lo = (g - hi.float()).to(torch.float16)
     packed = torch.stack([hi, lo], dim=2).contiguous()                 # [ks, bo, split, lane, 8]
     return packed.view(-1).view(torch.float32).clone()
+
+
+def block_exponent(*mats):
+    """Power-of-two exponent e for one weight matrix of the reference (all its 128x128 slices share it); the
+    slices are stored as 2^e W.  Matrices of ordinary scale (rms in [2^-4, 1), rms of the smallest 99 % of the
+    weights) keep e = 0 - the plain split, whose error on such weights is at fp32 rounding level; a smaller matrix is
+    lifted to rms 2^e W in [2^-4, 2^-3), where the fp16 `lo` halves of the weights that matter are no longer lost to
+    the subnormal range (representation error back to ~2^-22 relative to the matrix' scale); a larger one is brought
+    down to [1/2, 1), away from the fp16 maximum.  Lifting costs activation headroom (the accumulators and GELU
+    outputs of the layer carry 2^e), so it is not done where it is not needed.  The largest element must end up
+    <= 2^15; a matrix where that would push e more than MAX_RANGE_LOSS below the wanted value has no accurate split:
+    ValueError."""
+    a = torch.cat([m.detach().double().abs().reshape(-1) for m in mats])
+    if not bool(torch.isfinite(a).all()):
+        raise ValueError("non-finite weight: outside the fp16 range of the split-fp16 contraction modes")
+    mx = float(a.max())
+    if mx == 0.0:
+        return 0
+    # the scale of the bulk: rms of all but the largest 1 % (a few outliers must not decide the exponent of the rest)
+    bulk = a.sort().values[:max(1, int(0.99 * a.numel()))]
+    rms = max(float(bulk.pow(2).mean().sqrt()), mx * 2.0 ** -40)
+    lg = math.floor(math.log2(rms))
+    want = (-4 - lg) if lg < -4 else ((-1 - lg) if lg >= 0 else 0)
+    limit = 15 - math.ceil(math.log2(mx))                              # 2^e max|w| <= 2^15
+    if limit < want - MAX_RANGE_LOSS:
+        raise ValueError(f"weight matrix with max |w| / rms = {mx / rms:.3g} has no accurate fp16 hi/lo "
+                         "split (outside the fp16 range of the split-fp16 contraction modes); use precision='f32'")
+    return int(max(-MAX_CHAIN_EXP, min(MAX_CHAIN_EXP, min(want, limit))))
+
+
+def _chain(*es):
+    """Clamp exponents along an MLP so that the accumulated sums that reach a GELU (after the first and the second
+    layer) stay within +-MAX_CHAIN_EXP; a third layer's sum only scales a residual and a LayerNorm epsilon
+    (2^(2E) must be a normal fp32): +-40."""
+    out, acc = [], 0
+    for i, e in enumerate(es):
+        lim = MAX_CHAIN_EXP if i < 2 else 40
+        e = max(-lim - acc, min(lim - acc, e))
+        out.append(e)
+        acc += e
+    return out
 
 
 def strip_module_prefix(sd):
@@ -139,52 +183,93 @@ def denoiser_tensors(sd):
     return t
 
 
-def denoiser_tensors_h(sd, strict=True):
-    """Split-fp16 (hi/lo) copies of every 128x128 block, same names with an `h.` prefix.
-    strict=False (fp32-MFMA mode, where these copies are not read): a block outside the fp16 range is
-    stored as zeros and named in the returned dict's `unsplittable` list instead of raising."""
+def denoiser_tensors_h(sd, strict=True, use_exponents=True):
+    """Split-fp16 (hi/lo) copies of every 128x128 block with their block exponents applied, the matching
+    pre-scaled biases, same names with an `h.` prefix (layout: include/codlad_hip.h, codlad_enc_layer_h).
+    Returns (tensors, exponents {layer: {name: e}}, n_unsplittable).
+    strict=False (fp32-MFMA mode, where these copies are not read): a layer whose weights have no fp16 split is
+    stored as zeros and counted instead of raising.  use_exponents=False packs every block with e = 0 (the
+    plain split, for A/B measurements)."""
     sd = strip_module_prefix(sd)
-    bad = []
-    _strict_pack = globals()["pack_block_h"]
+    g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
+    t, exps = OrderedDict(), OrderedDict()
+    bad = [0]
 
-    def pack_block_h(w, scale=1.0):  # noqa: F811  (shadows the module function inside this builder only)
+    def expo(*mats):
+        return block_exponent(*mats) if use_exponents else 0
+
+    def pk(w, e, scale=1.0):
+        return pack_block_h(w, scale * 2.0 ** e)
+
+    def layer(prefix, build):
         try:
-            return _strict_pack(w, scale)
+            build()
         except ValueError:
             if strict:
                 raise
-            bad.append(tuple(w.shape))
-            return torch.zeros(H * H, dtype=torch.float32)
+            bad[0] += 1
+            for k in [k for k in t if k.startswith(prefix)]:
+                del t[k]
+            build(zero=True)
 
-    g = lambda k: sd[k].detach().float().cpu().contiguous()  # noqa: E731
-    t = OrderedDict()
     for l in range(3):
-        p = f"encoder_layers.{l}"
-        W1, W11 = g(f"{p}.W1.weight"), g(f"{p}.W11.weight")
-        e = f"h.enc{l}."
-        t[e + "W1e"] = pack_block_h(W1[:, 128:256]); t[e + "W2"] = pack_block_h(g(f"{p}.W2.weight"))
-        t[e + "W3"] = pack_block_h(g(f"{p}.W3.weight"))
-        t[e + "W11e"] = pack_block_h(W11[:, 128:256]); t[e + "W12"] = pack_block_h(g(f"{p}.W12.weight"))
-        t[e + "W13"] = pack_block_h(g(f"{p}.W13.weight"))
-        t[e + "W1a"] = pack_block_h(W1[:, 0:128]); t[e + "W1c"] = pack_block_h(W1[:, 256:384])
-        t[e + "W11a"] = pack_block_h(W11[:, 0:128]); t[e + "W11c"] = pack_block_h(W11[:, 256:384])
-        Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
-        for c in range(4):
-            t[e + f"Win{c}"] = pack_block_h(Win[128 * c:128 * c + 128, :])
-            t[e + f"Wout{c}"] = pack_block_h(Wout[:, 128 * c:128 * c + 128])
+        p, e_ = f"encoder_layers.{l}", f"h.enc{l}."
+
+        def build(zero=False, p=p, e_=e_, l=l):
+            W1, W11 = g(f"{p}.W1.weight"), g(f"{p}.W11.weight")
+            W2, W3, W12, W13 = (g(f"{p}.{n}.weight") for n in ("W2", "W3", "W12", "W13"))
+            Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
+            if zero:
+                Z = torch.zeros(H, H)
+                W1, W11, Win, Wout = Z.repeat(1, 3), Z.repeat(1, 3), Z.repeat(4, 1), Z.repeat(1, 4)
+                W2 = W3 = W12 = W13 = Z
+            e1, e2 = _chain(expo(W1), expo(W2))
+            e11, e12, e13 = _chain(expo(W11), expo(W12), expo(W13))
+            e_in, e_out = _chain(expo(Win), expo(Wout))
+            e3 = expo(W3)                      # node kernel: taken out by a constant multiply, never reaches a GELU
+            exps[f"enc{l}"] = dict(e1=e1, e2=e2, e3=e3, e11=e11, e12=e12, e13=e13, e_in=e_in, e_out=e_out)
+            t[e_ + "W1e"] = pk(W1[:, 128:256], e1); t[e_ + "W2"] = pk(W2, e2); t[e_ + "W3"] = pk(W3, e3)
+            t[e_ + "W11e"] = pk(W11[:, 128:256], e11); t[e_ + "W12"] = pk(W12, e12); t[e_ + "W13"] = pk(W13, e13)
+            t[e_ + "W1a"] = pk(W1[:, 0:128], e1); t[e_ + "W1c"] = pk(W1[:, 256:384], e1)
+            t[e_ + "W11a"] = pk(W11[:, 0:128], e11); t[e_ + "W11c"] = pk(W11[:, 256:384], e11)
+            for c in range(4):
+                t[e_ + f"Win{c}"] = pk(Win[128 * c:128 * c + 128, :], e_in)
+                t[e_ + f"Wout{c}"] = pk(Wout[:, 128 * c:128 * c + 128], e_out)
+            for b, k, e in (("b1", "W1", e1), ("b2", "W2", e1 + e2), ("b3", "W3", e3), ("b11", "W11", e11),
+                            ("b12", "W12", e11 + e12), ("b13", "W13", e11 + e12 + e13),
+                            ("b_in", "dense.W_in", e_in), ("b_out", "dense.W_out", e_in + e_out)):
+                t[e_ + b] = (torch.zeros_like(g(f"{p}.{k}.bias")) if zero else g(f"{p}.{k}.bias")) * 2.0 ** e
+
+        layer(e_, build)
+    Ws = g("W_s.weight")
     for l in range(3):
-        p = f"decoder_layers.{l}"
-        W1 = g(f"{p}.W1.weight")
-        d = f"h.dec{l}."
-        t[d + "W1e"] = pack_block_h(W1[:, 128:256], 2.0)
-        t[d + "W2"] = pack_block_h(g(f"{p}.W2.weight")); t[d + "W3"] = pack_block_h(g(f"{p}.W3.weight"))
-        t[d + "W1a"] = pack_block_h(W1[:, 0:128]); t[d + "W1v"] = pack_block_h(W1[:, 384:512])
-        Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
-        for c in range(4):
-            t[d + f"Win{c}"] = pack_block_h(Win[128 * c:128 * c + 128, :])
-            t[d + f"Wout{c}"] = pack_block_h(Wout[:, 128 * c:128 * c + 128])
-    t.unsplittable = len(bad)
-    return t
+        p, d_ = f"decoder_layers.{l}", f"h.dec{l}."
+
+        def build(zero=False, p=p, d_=d_, l=l):
+            W1 = g(f"{p}.W1.weight")
+            W2, W3 = g(f"{p}.W2.weight"), g(f"{p}.W3.weight")
+            Win, Wout = g(f"{p}.dense.W_in.weight"), g(f"{p}.dense.W_out.weight")
+            if zero:
+                Z = torch.zeros(H, H)
+                W1, Win, Wout, W2, W3 = Z.repeat(1, 4), Z.repeat(4, 1), Z.repeat(1, 4), Z, Z
+            # h_ESV = [h_E|h_S_j|h_V_j] + [h_E|h_S_j|h_Venc_j] (latent_model.py:260-261): h_E and h_S doubled
+            e1, e2 = _chain(expo(W1[:, 0:128], 2.0 * W1[:, 128:256], W1[:, 384:512]), expo(W2))
+            e_in, e_out = _chain(expo(Win), expo(Wout))
+            e3 = expo(W3)
+            exps[f"dec{l}"] = dict(e1=e1, e2=e2, e3=e3, e_in=e_in, e_out=e_out)
+            t[d_ + "W1e"] = pk(W1[:, 128:256], e1, 2.0)
+            t[d_ + "W2"] = pk(W2, e2); t[d_ + "W3"] = pk(W3, e3)
+            t[d_ + "W1a"] = pk(W1[:, 0:128], e1); t[d_ + "W1v"] = pk(W1[:, 384:512], e1)
+            t[d_ + "TS"] = (F.linear(2.0 * Ws, W1[:, 256:384]) * 2.0 ** e1).contiguous()
+            for c in range(4):
+                t[d_ + f"Win{c}"] = pk(Win[128 * c:128 * c + 128, :], e_in)
+                t[d_ + f"Wout{c}"] = pk(Wout[:, 128 * c:128 * c + 128], e_out)
+            for b, k, e in (("b1", "W1", e1), ("b2", "W2", e1 + e2), ("b3", "W3", e3),
+                            ("b_in", "dense.W_in", e_in), ("b_out", "dense.W_out", e_in + e_out)):
+                t[d_ + b] = (torch.zeros_like(g(f"{p}.{k}.bias")) if zero else g(f"{p}.{k}.bias")) * 2.0 ** e
+
+        layer(d_, build)
+    return t, exps, bad[0]
 
 
 def decoder_tensors(sd):
@@ -253,12 +338,13 @@ DEFAULT_PRECISION = "f16x3"
 
 
 class DenoiserWeights:
-    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION):
+    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION, block_exponents=True):
         if precision not in PRECISIONS:
             raise ValueError(f"precision {precision!r}: one of {sorted(PRECISIONS)}")
         tensors = denoiser_tensors(state_dict)
-        split = denoiser_tensors_h(state_dict, strict=precision != "f32")
-        self.splittable = split.unsplittable == 0      # False: some block does not fit fp16, fp32-MFMA mode only
+        split, self.exponents, n_bad = denoiser_tensors_h(state_dict, strict=precision != "f32",
+                                                          use_exponents=block_exponents)
+        self.splittable = n_bad == 0      # False: some layer has no fp16 split, fp32-MFMA mode only
         tensors.update(split)
         self.blob = Blob(tensors, device)
         self.precision = precision
@@ -284,10 +370,15 @@ class DenoiserWeights:
                 e.Win[c], e.Wout[c] = p(f"enc{l}.Win{c}"), p(f"enc{l}.Wout{c}")
                 d.Win[c], d.Wout[c] = p(f"dec{l}.Win{c}"), p(f"dec{l}.Wout{c}")
             eh, dh = w.enc_h[l], w.dec_h[l]
-            for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c"):
+            for n in ("W1e", "W2", "W3", "W11e", "W12", "W13", "W1a", "W1c", "W11a", "W11c",
+                      "b1", "b2", "b3", "b11", "b12", "b13", "b_in", "b_out"):
                 setattr(eh, n, p(f"h.enc{l}.{n}"))
-            for n in ("W1e", "W2", "W3", "W1a", "W1v"):
+            for n in ("W1e", "W2", "W3", "W1a", "W1v", "TS", "b1", "b2", "b3", "b_in", "b_out"):
                 setattr(dh, n, p(f"h.dec{l}.{n}"))
+            for n, e in self.exponents[f"enc{l}"].items():
+                setattr(eh, n, e)
+            for n, e in self.exponents[f"dec{l}"].items():
+                setattr(dh, n, e)
             for c in range(4):
                 eh.Win[c], eh.Wout[c] = p(f"h.enc{l}.Win{c}"), p(f"h.enc{l}.Wout{c}")
                 dh.Win[c], dh.Wout[c] = p(f"h.dec{l}.Win{c}"), p(f"h.dec{l}.Wout{c}")

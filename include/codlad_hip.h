@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 4
+#define CODLAD_ABI_VERSION 5
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -73,15 +73,33 @@ typedef struct {
 
 /* Split-fp16 copies of the 128x128 blocks: each weight split into hi + lo fp16 halves, 64 KB per
  * block in the order [k-step 0..7][out block 0..3][hi,lo][lane 0..63][8 halves]
- * (codlad_amd/csrc/common.h).  Used when codlad_denoiser_weights.precision is 1 or 2. */
+ * (codlad_amd/csrc/common.h).  Used when codlad_denoiser_weights.precision is 1 or 2.
+ *
+ * BLOCK EXPONENTS.  hi + lo reproduces a value to max(2^-22 |x|, 2^-25): the bound is the relative one only
+ * while the `lo` half is a normal fp16 (|x| >~ 2^-3).  So that this holds whatever the scale of a layer's
+ * weights, every block is stored multiplied by a power of two 2^e chosen when the weights are packed (one e
+ * per weight matrix of the reference: e1 for the three slices of W1, e2 for W2, ...; codlad_amd/weights.py),
+ * the biases are stored pre-multiplied by the power of two their accumulator carries, and the activations
+ * between the layers of an MLP carry the accumulated exponent through an exactly scale-equivariant GELU
+ * evaluation.  The scale leaves where that is free (a LayerNorm, a constant multiply).  Exact power-of-two
+ * scaling throughout: with every e = 0 the arithmetic is the unscaled one bit for bit.  Consequences visible
+ * at this boundary: in the split modes the workspace's S and PQ buffers and E1 hold scaled values
+ * (S: 2^(e1+e2) of the layer that wrote it; PQ: 2^e1 / 2^e11; E1[0] / E1[1]: 2^e1 / 2^e11 of encoder layer 0). */
 typedef struct {
     const void *W1e, *W2, *W3, *W11e, *W12, *W13, *W1a, *W1c, *W11a, *W11c;
     const void *Win[4], *Wout[4];
+    /* 2^e1 b1, 2^(e1+e2) b2, 2^e3 b3, 2^e11 b11, 2^(e11+e12) b12, 2^(e11+e12+e13) b13, 2^e_in b_in [512],
+     * 2^(e_in+e_out) b_out */
+    const float *b1, *b2, *b3, *b11, *b12, *b13, *b_in, *b_out;
+    int e1, e2, e3, e11, e12, e13, e_in, e_out;
 } codlad_enc_layer_h;
 
 typedef struct {
     const void *W1e, *W2, *W3, *W1a, *W1v;
     const void *Win[4], *Wout[4];
+    const float *TS;                   /* 2^e1 TS                                              */
+    const float *b1, *b2, *b3, *b_in, *b_out;   /* scaled like the encoder's                  */
+    int e1, e2, e3, e_in, e_out;
 } codlad_dec_layer_h;
 
 /* Replaces the parameters of reference models/latent_model.py:119-148 (ProteinMPNN_diffusion_new). */
@@ -100,11 +118,14 @@ typedef struct {
     codlad_enc_layer enc[3];
     codlad_dec_layer dec[3];
     /* 0: contractions on v_mfma_f32_32x32x2_f32 (exact fp32 products);
-     * 1: f16x4 - both operands split into two fp16 halves (representation error <= 2^-22), the four
-     *    cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate;
+     * 1: f16x4 - both operands split into two fp16 halves (representation error max(2^-22 |x|, 2^-25),
+     *    kept in its relative regime by the block exponents below), the four cross products on
+     *    v_mfma_f32_32x32x16_f16, fp32 accumulate;
      * 2: f16x3 - the same without the lo x lo product, which is itself <= 2^-22 of the result: a
      *    quarter fewer matrix instructions at the same measured deviation from mode 0.
-     *    The default of the Python host layer. */
+     *    The default of the Python host layer.
+     * Operands beyond the fp16 range (65504) cannot be split: weights are refused when packed, activations
+     * are caught by the status word (codlad_status_check). */
     int precision;
     codlad_enc_layer_h enc_h[3];
     codlad_dec_layer_h dec_h[3];

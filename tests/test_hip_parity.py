@@ -206,10 +206,13 @@ def test_hoisted_layer0_edge_terms(den, sd):
     K = torch.tensor([40] * 40 + [64] * 87, device=DEV)
     valid = (torch.arange(64, device=DEV)[None, :] < K[:, None])
     hE = engine.edge_rows(st.h_E0).double()
+    ex = den.weights.exponents["enc0"]
     for which, name in enumerate(["W1", "W11"]):
         W = sd[f"encoder_layers.0.{name}.weight"][:, 128:256].to(DEV).double()
         want = hE @ W.T
-        got = engine.edge_rows(st.E1[which]).double()
+        # in the split-fp16 modes E1 carries the layer's block exponent (include/codlad_hip.h)
+        scale = 1.0 if den.weights.precision == "f32" else 2.0 ** -ex["e1" if which == 0 else "e11"]
+        got = engine.edge_rows(st.E1[which]).double() * scale
         err = ((got - want).abs() * valid[..., None]).max() / want.abs().max()
         assert float(err) < 2e-6, (name, float(err))
     plain = den.prepare_structures([xa, xb], [za, zb], hoist_layer0=False)

@@ -40,6 +40,7 @@ def test_struct_layouts_match_header():
     assert _lib.DenoiserWeights.precision.offset == out[3]
     assert _lib.DenoiserWeights.enc_h.offset == out[4]
     assert C.sizeof(_lib.EncLayer) == 26 * 8 and C.sizeof(_lib.DecLayer) == 19 * 8
+    assert C.sizeof(_lib.EncLayerH) == 26 * 8 + 8 * 4 and C.sizeof(_lib.DecLayerH) == 19 * 8 + 5 * 4 + 4
 
 
 def test_argument_errors_are_reported_not_crashed():
@@ -205,20 +206,48 @@ def test_edge_block_layout_helper():
 
 
 def test_split_pack_refuses_weights_outside_fp16_range():
-    """hi = f16(w) would be inf: the split-fp16 packer raises; the non-strict builder (fp32-MFMA mode) counts."""
-    from codlad_amd.weights import denoiser_tensors_h, pack_block_h
+    """hi = f16(w) would be inf: the split-fp16 packer raises; a weight matrix gets a power-of-two block exponent
+    that brings its rms to [1/4, 1/2) and its largest element inside the fp16 range - or is refused when one outlier
+    would cost the rest of the matrix its precision; the non-strict builder (fp32-MFMA mode) counts instead."""
+    from codlad_amd.weights import block_exponent, denoiser_tensors_h, pack_block_h
     W = torch.zeros(128, 128)
     W[2, 3] = 7.0e4
     with pytest.raises(ValueError, match="fp16 range"):
         pack_block_h(W)
     pack_block_h(W, 0.5)                                   # 3.5e4 fits
+    g = torch.Generator().manual_seed(8)
+    for rms in (3e-4, 0.02, 0.09, 0.7, 1.5, 40.0):
+        M = torch.randn(128, 384, generator=g) * rms
+        e = block_exponent(M)
+        assert (e == 0) == (0.07 < rms < 0.9), (rms, e)           # ordinary scale: the plain split
+        assert 2.0 ** -4.2 <= float(M.pow(2).mean().sqrt()) * 2.0 ** e < 1.05, (rms, e)
+    M = torch.randn(128, 128, generator=g) * 1e-3
+    e_plain = block_exponent(M)
+    M[0, 0] = 1.0e4                                        # an outlier the block can absorb: 2^e max <= 2^15 limits e
+    assert block_exponent(M) == 1 and e_plain == 7
+    M[0, 0] = 1.0e9
+    with pytest.raises(ValueError, match="fp16 range"):
+        block_exponent(M)
     sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
-    assert denoiser_tensors_h(sd).unsplittable == 0
+    t, exps, bad = denoiser_tensors_h(sd)
+    assert bad == 0 and set(exps) == {f"{k}{l}" for k in ("enc", "dec") for l in range(3)}
+    assert all(v == 0 for d in exps.values() for v in d.values())      # the default synthetic weights are ordinary
+    exps_small = denoiser_tensors_h(cases.envelope_state_dict("small_first_1e-2"))[1]
+    assert exps_small["enc0"]["e1"] > 0 > exps_small["enc0"]["e2"]
+    # biases are stored with the power of two their accumulator carries
+    sd_s = cases.envelope_state_dict("small_first_1e-2")
+    t_s, ex_s, _ = denoiser_tensors_h(sd_s)
+    e = ex_s["enc1"]
+    assert torch.equal(t_s["h.enc1.b12"], sd_s["encoder_layers.1.W12.bias"] * 2.0 ** (e["e11"] + e["e12"]))
+    # ... and e = 0 everywhere is the plain split
+    t0, exps0, _ = denoiser_tensors_h(sd, use_exponents=False)
+    assert all(v == 0 for d in exps0.values() for v in d.values())
+    assert torch.equal(t0["h.enc1.W2"], pack_block_h(sd["encoder_layers.1.W2.weight"]))
     sd["decoder_layers.2.dense.W_out.weight"] = sd["decoder_layers.2.dense.W_out.weight"].clone()
-    sd["decoder_layers.2.dense.W_out.weight"][0, 300] = -1.0e5
+    sd["decoder_layers.2.dense.W_out.weight"][0, 300] = float("inf")
     with pytest.raises(ValueError, match="fp16 range"):
         denoiser_tensors_h(sd)
-    assert denoiser_tensors_h(sd, strict=False).unsplittable == 1
+    assert denoiser_tensors_h(sd, strict=False)[2] == 1
 
 
 def test_cli_batches_of_one_file_get_distinct_output_names():

@@ -78,11 +78,30 @@ def test_fp16_range_overflow_is_an_error_not_a_number(precision):
 
 
 def test_weights_beyond_fp16_range_are_refused_at_pack_time():
-    """A weight that does not fit the fp16 `hi` half cannot be split: packing raises instead of storing inf."""
+    """A weight matrix with no accurate fp16 hi/lo split (an element that no block exponent brings into range without
+    costing the rest its precision) is refused when packed, instead of storing inf or garbage."""
     sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
     sd["encoder_layers.1.W2.weight"] = sd["encoder_layers.1.W2.weight"].clone()
-    sd["encoder_layers.1.W2.weight"][3, 5] = 7.0e4
+    sd["encoder_layers.1.W2.weight"][3, 5] = 1.0e9
     with pytest.raises(ValueError, match="fp16 range"):
         Denoiser(sd, DEV, precision="f16x3")
     den = Denoiser(sd, DEV, precision="f32")                           # the fp32-MFMA mode takes it
     assert den.weights.precision == "f32"
+
+
+def test_block_exponents_are_what_keeps_small_layers_accurate():
+    """With every block exponent 0 (the plain hi/lo split) a net whose first MLP layers are small but carry the signal
+    misses the 1e-5 bar (the `lo` halves of its weights are subnormal fp16: absolute, not relative, precision); with
+    the exponents it is as accurate as on ordinary weights.  On ordinary weights the two differ by rounding only."""
+    L, B, seed = cases.ENVELOPE_GEOMETRY
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    xd = x.reshape(-1, 3).to(DEV)
+    errs = {}
+    for name in ("small_first_1e-2", "xavier"):
+        gold = np.load(cases.npz_path(f"g10_envelope_{name}"))["out"]
+        for on in (False, True):
+            den = Denoiser(cases.envelope_state_dict(name), DEV, precision="f16x3", block_exponents=on)
+            out = den.forward(job_of(den, prot, B), xd, int(t[0])).cpu().view(B, L, 6)
+            errs[name, on] = rel_err(out, gold)
+    assert errs["small_first_1e-2", True] < 5e-6 < 1e-5 < errs["small_first_1e-2", False], errs
+    assert errs["xavier", True] < 5e-6 and errs["xavier", False] < 5e-6, errs
