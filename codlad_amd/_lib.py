@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 5   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 6   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -52,7 +52,7 @@ class DenoiserWeights(C.Structure):
 
 
 class Workspace(C.Structure):
-    _fields_ = [(n, P) for n in ("hV", "hVenc", "S", "PQ", "hE", "status")]
+    _fields_ = [(n, P) for n in ("hV", "hVenc", "S", "PQ", "hE", "status", "tile_list")] + [("n_tiles", C.c_int32)]
 
 
 class DecoderWeights(C.Structure):
@@ -87,6 +87,7 @@ _SIGS = {
     "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P,
                                           C.POINTER(Workspace), P]),
     "codlad_status_check": (C.c_int, [P, P]),
+    "codlad_set_option": (C.c_int, [C.c_int, C.c_int]),
     "codlad_ddpm_update": (C.c_int, [P, P, P, P, C.c_int, P, P, P]),
     "codlad_sample_loop": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P, P,
                                      C.c_int, C.POINTER(Workspace), P]),
@@ -120,6 +121,14 @@ def lib():
             raise RuntimeError("libcodlad_hip.so ABI version mismatch")
         _lib = handle
     return _lib
+
+
+OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES = 0, 1      # CODLAD_OPT_* of include/codlad_hip.h
+
+
+def set_option(option, value):
+    """Tuning switch of the library (speed only; include/codlad_hip.h codlad_set_option)."""
+    check(lib().codlad_set_option(option, value), "codlad_set_option")
 
 
 def exported_symbols():

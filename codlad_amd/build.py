@@ -9,7 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
-SOURCES = ["api.hip", "denoiser_kernels.hip", "features_kernels.hip", "decode_kernels.hip", "metrics_kernels.hip"]
+SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_tile_kernels.hip", "node_wide_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
+           "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
 # and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
 EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"],
@@ -18,8 +19,11 @@ EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hi
                # the packed math that pays (GELU) is written out explicitly in common.h
                # -fno-honor-nans: min/max on MFMA results otherwise get a canonicalising v_max x,x
                # each (3 instructions for min(|x|, c)); nothing on this path produces or tests NaN
-               "denoiser_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "codlad_hip.h")]
+               "denoiser_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               "edge_tile_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               "node_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_args.h"), os.path.join(CSRC, "node_args.h"),
+           os.path.join(HERE, "..", "include", "codlad_hip.h")]
 
 
 def hipcc():
@@ -27,6 +31,33 @@ def hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+RESOURCES = os.path.join(CSRC, "kernel_resources.json")
+
+
+def record_resources(source, remarks):
+    """Registers / scratch / occupancy hipcc reports per kernel (-Rpass-analysis=kernel-resource-usage), kept
+    beside the objects: the edge kernels sit at the 256-register limit and a few spilled registers in their inner
+    loops cost ~10 % (tests/test_host_logic.py holds them to their budget)."""
+    import json
+    import re
+    table = {}
+    if os.path.exists(RESOURCES):
+        with open(RESOURCES) as f:
+            table = json.load(f)
+    table = {k: v for k, v in table.items() if v.get("source") != source}
+    cur = None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = table.setdefault(m.group(1), {"source": source})
+            continue
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    with open(RESOURCES, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
 
 
 def stale():
@@ -48,10 +79,14 @@ def build(force=False, verbose=True):
                 os.path.getmtime(d) for d in [src] + HEADERS):
             cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(s, []) + \
                   os.environ.get("CODLAD_CXXFLAGS", "").split() + \
-                  ["-c", src, "-o", obj]
+                  ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            if res.returncode:
+                sys.stderr.write(res.stderr)
+                raise subprocess.CalledProcessError(res.returncode, cmd)
+            record_resources(s, res.stderr)
         objs.append(obj)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:

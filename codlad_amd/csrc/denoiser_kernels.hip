@@ -9,34 +9,11 @@
 // Per edge this leaves 2 (message) or 3 (edge update) 128x128 contractions, all on
 // v_mfma_f32_32x32x2_f32 through the register chain of common.h.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/codlad_hip.h"
 
-#define HD 128
+#include "edge_args.h"
 
-// ---------------------------------------------------------------------------------------------
-// Edge kernels: one wave = one node = up to 64 neighbour columns (two 32-column passes).
-// ---------------------------------------------------------------------------------------------
-struct EdgeArgs {
-    const int4 *node_info;
-    const int32_t *E_idx;  // [n_snodes][64]
-    const float *hE_in;    // [rows][64][128]
-    int in_by_src;         // 1: rows indexed by structure node (h_E0), 0: by sample node
-    const float *E1;       // encoder layer 0 only (may be null): W1e @ h_E0 per structure edge, hoisted
-    float *hE_out;         // edge update only
-    const float *P, *Q;    // [n_nodes][128]: own-node term (+bias), neighbour term
-    const float *W1, *W2, *W3;
-    const void *W1h, *W2h, *W3h;  // split-fp16 copies (precision 1, 2)
-    const float *b2, *b3;
-    const float *mods3;    // edge update: shift3, scale3, gate3 (3 x 128)
-    float *S;              // message: [n_nodes][128]
-    int n_nodes;
-    // split-fp16 modes (block exponents, common.h): GELU constants for the input of layer 2 (scale 2^E1) and of
-    // layer 3 / the message epilogue (2^(E1+E2)); edge update: the residual enters layer 3's accumulator as
-    // h_E * res_scale (= 2^(E1+E2+E3)) and the LayerNorm runs with eps * res_scale^2 (exactly equivalent).
-    // b2 / b3 point at biases pre-scaled to match.
-    GeluK gelu_a, gelu_b;
-    float res_scale, ln_eps;
-};
 
 template <bool EDGE_UPDATE>
 __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
@@ -103,56 +80,6 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
 // stream from L2, see below) - and every wave walks its nodes with a stride (wave_node_span).  The
 // contraction runs on the f16 matrix pipe, split / bias / GELU / reduction on the fp32 lanes.
 // ---------------------------------------------------------------------------------------------
-#define LDS_BLOCK_U4 4096   // one 64 KB packed block in 16-byte words
-
-// XCD-aware node placement.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
-// share one, MI355X_MICROARCH.md "Workgroup dispatch"), each with a private 4 MB L2.  The node list
-// is cut into 8 contiguous chunks and chunk b % 8 is served by the workgroups of that residue
-// class, in the node kernel and in both edge kernels alike: the P/Q rows the node kernel writes,
-// the neighbour rows an edge tile gathers (neighbours are nodes of the same sample, i.e. of the
-// same chunk) and the edge state written by one edge kernel and read by the next then stay within
-// one XCD's L2 instead of being pulled into all eight.  Placement is a speed matter only.
-// Chunk granularity: large jobs use 256 nodes (the largest node-kernel workgroup: 8 waves x 32), so
-// that the node kernel can follow the same chunks; below 32 768 nodes that would leave whole XCDs
-// without work (eight chunks of a multiple of 256 nodes), so chunks are cut to 32 nodes and the node
-// kernel keeps its plain order - at that size everything fits in any L2 anyway.
-constexpr int NODE_WG_TILE = 256;
-constexpr int XCD_CHUNKED_NODE_KERNEL_MIN = 32768;
-__host__ __device__ inline int xcd_chunk_nodes(int n_nodes) {
-    const int g = n_nodes >= XCD_CHUNKED_NODE_KERNEL_MIN ? NODE_WG_TILE : 32;
-    const int tiles = (n_nodes + g - 1) / g;
-    return g * ((tiles + 7) / 8);
-}
-
-struct NodeSpan {
-    int first, end, stride;
-};
-// nodes first, first + stride, ... < end for wave `wave` of this workgroup
-DEV NodeSpan wave_node_span(int n_nodes, int nwaves, int wave) {
-    const int nb = gridDim.x, b = blockIdx.x;
-    if (nb % 8) return {b * nwaves + wave, n_nodes, nb * nwaves};
-    const int chunk = xcd_chunk_nodes(n_nodes);
-    const int lo = (b % 8) * chunk, hi = lo + chunk < n_nodes ? lo + chunk : n_nodes;
-    return {lo + (b / 8) * nwaves + wave, hi, (nb / 8) * nwaves};
-}
-
-// Small wave-uniform vectors (the centre node's P row, biases, modulation) are NOT read with
-// per-lane global loads: a 128-float vector costs 16 dwordx4 instructions per lane whatever the
-// addresses, and eight of those per tile were half of the kernel's traffic through the texture
-// addresser (tools/ablate_edge.py).  They sit in LDS instead and are read as broadcasts.
-//   message LDS (16-byte words): [W1e 4096][W2 4096][consts][P slots NWAVES x 32]
-//   update  LDS                : [W12 4096][W13 4096][W11e first UPD_W1_KS k-steps][consts][P slots]
-// Three blocks do not fit in 160 KB, so the update kernel streams part of ONE block from L2.  That
-// block is W11e, the first contraction of a tile: its fragment loads are issued before the tile's
-// own rows are even requested and run eight groups ahead (the registers are free at that point),
-// which hides the L2 latency that a streamed W13 - needed last, with three tiles live - could not.
-constexpr int UPD_W1_KS = 3;                              // k-steps of W11e that fit in LDS
-constexpr int EDGE_CONST_U4 = 4 * 32;                     // b2, b3, modulate A, modulate B
-template <bool EDGE_UPDATE, int NWAVES>
-constexpr int edge_lds_u4() {
-    return 2 * LDS_BLOCK_U4 + (EDGE_UPDATE ? UPD_W1_KS * 512 : 0) + EDGE_CONST_U4 + NWAVES * 32;
-}
-
 // Edge update, split-fp16 contractions:
 //   h_E[n,j] <- mod3(LN(h_E[n,j] + W13 GELU(W12 GELU(P_i + Q_j + W11e h_E[n,j]) + b12) + b13))
 // HOISTED: encoder layer 0 with a.E1 given - layer 1's edge contraction comes precomputed.
@@ -375,36 +302,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
 //   MODE_UPD: h_V = mod2(LN(v + FFN(v))),  v = mod1(LN(h_V + (W3 @ S + K b3) / 30))
 // then up to four 128x128 projections of the new h_V for the next edge kernels.
 // ---------------------------------------------------------------------------------------------
-struct NodeArgs {
-    const int4 *node_info;
-    int n_nodes;
-    const float *x, *x_in_w, *x_in_b;  // MODE_IN
-    const float *x_sc;                 // MODE_IN with self-conditioning: previous pred_xstart (null = zeros)
-    int in_dim;                        // 3, or 6 = [x_self_cond | x] (latent_model.py:210-212)
-    const float *S;                    // MODE_UPD
-    float *hV;
-    const float *W3, *b3;
-    const float *mods;                 // shift1, scale1, gate1, shift2, scale2, gate2
-    const float *Win[4], *Wout[4];
-    const float *b_in, *b_out;
-    int n_proj;
-    const float *proj_w[4];
-    const float *proj_b[4];            // may be null
-    float *proj_out[4];
-    int proj_flags[4];                 // bit0: input = h_V + h_Venc; bit1: += TS[z]
-    const float *TS;                   // [30][128]
-    const float *hVenc_in;
-    float *hVenc_out;                  // if set: also store the new h_V here (h_Venc := h_V)
-    int venc_is_self;                  // h_Venc == new h_V (first decoder layer's Q)
-    // precision 1, 2: split-fp16 copies of the blocks in execution order: [W3, Win0, Wout0, .., Wout3,] proj0..
-    const void *blk_h[13];
-    // block exponents (split-fp16 modes; all 1 / plain in the fp32 mode): S arrives scaled by the message MLP's
-    // accumulated exponent and is contracted as S * s_scale (= 2^-(E1+E2) / 64); the W3 term comes out as
-    // t * 2^e3 / 64 and is added as (t * t_scale) / 30 (t_scale = 64 * 2^-e3); the FFN output carries
-    // 2^(e_in+e_out) and is added as t * ffn_scale.  b3, b_in, b_out, proj_b, TS are pre-scaled to match.
-    float s_scale, t_scale, ffn_scale;
-    GeluK gelu_ffn;
-};
+#include "node_args.h"
 
 template <bool MODE_UPD>
 __global__ __launch_bounds__(64, 1) void node_kernel(NodeArgs a) {
@@ -584,6 +482,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void node_kernel_h(NodeArgs 
     } else {
         Tile s, t;
         tile_load_row(s, a.S + (size_t)nc * HD, h);
+        if (a.s_partials) {       // tile kernels: planes half + 2 h, added in msg_kernel_h's order (a0 + a1) + (b0 + b1)
+            const size_t plane = (size_t)a.n_nodes * HD;
+            tile_load_row(t, a.S + 2 * plane + (size_t)nc * HD, h);
+            if (info.z > 32) {
+                tile_add_row(s, a.S + plane + (size_t)nc * HD, h);
+                tile_add_row(t, a.S + 3 * plane + (size_t)nc * HD, h);
+            }
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) s.b[bo] += t.b[bo];
+        }
         tile_load_row(t, a.b3, h);
         // S is a sum over up to 64 neighbours and the only operand of the path that is not
         // normalised: contract W3 with S/64 (exact power-of-two scaling, undone below) so that the
@@ -654,41 +562,35 @@ struct FinalArgs {
     int *status;        // sticky status word or null (CODLAD_STATUS_NONFINITE)
 };
 
+// 32 lanes per node (one 16-byte word of the row each: coalesced 512-byte row reads, the reductions are
+// butterflies inside the half wave), 8 nodes per 256-thread block.
+DEV float half_wave_allsum(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= a.n_nodes) return;
-    const float4 *row = reinterpret_cast<const float4 *>(a.hV + (size_t)n * HD);
-    float s = 0.f;
-    for (int i = 0; i < 32; ++i) {
-        const float4 v = row[i];
-        s += (v.x + v.y) + (v.z + v.w);
-    }
-    const float mean = s * (1.0f / 128.0f);
-    float var = 0.f;
-    for (int i = 0; i < 32; ++i) {
-        const float4 v = row[i];
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
+    const int l = threadIdx.x & 31;
+    const int n = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = n < a.n_nodes;
+    const int nc = live ? n : a.n_nodes - 1;           // whole half waves stay converged for the shuffles
+    const float4 v = reinterpret_cast<const float4 *>(a.hV + (size_t)nc * HD)[l];
+    const float mean = half_wave_allsum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    const float var = half_wave_allsum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + 1e-6f);
+    const float4 sh = reinterpret_cast<const float4 *>(a.mods)[l], sc = reinterpret_cast<const float4 *>(a.mods + HD)[l];
+    const float m0 = (d0 * rstd) * (1.0f + sc.x) + sh.x, m1 = (d1 * rstd) * (1.0f + sc.y) + sh.y,
+                m2 = (d2 * rstd) * (1.0f + sc.z) + sh.z, m3 = (d3 * rstd) * (1.0f + sc.w) + sh.w;
     float o[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = 0.f;
-    const float *shift = a.mods, *scale = a.mods + HD;
-    for (int i = 0; i < 32; ++i) {
-        const float4 v = row[i];
-        const float y[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = 4 * i + e;
-            const float m = ((y[e] - mean) * rstd) * (1.0f + scale[f]) + shift[f];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = fmaf(m, a.out_w[k * HD + f], o[k]);
-        }
+    for (int k = 0; k < 6; ++k) {
+        const float4 w = reinterpret_cast<const float4 *>(a.out_w + k * HD)[l];
+        o[k] = half_wave_allsum(fmaf(m3, w.w, fmaf(m2, w.z, fmaf(m1, w.y, m0 * w.x)))) + a.out_b[k];
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] += a.out_b[k];
-    if (a.status) {
+    if (!live) return;
+    if (a.status && l == 0) {
         // inf / NaN by exponent bits.  This file is built with -fno-honor-nans: the compiler folds x != x away and
         // even turns the bit test on a float's bits into |x| == inf (false for NaN), so the bits are laundered
         // through an empty asm and tested as the integers they then are.
@@ -702,14 +604,20 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
         if (bad) atomicOr(a.status, CODLAD_STATUS_NONFINITE);
     }
     if (a.logits) {
+        if (l < 6) {
+            float mine = o[0];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a.logits[(size_t)n * 6 + k] = o[k];
+            for (int k = 1; k < 6; ++k) mine = l == k ? o[k] : mine;
+            a.logits[(size_t)n * 6 + l] = mine;
+        }
         return;
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        a.x[(size_t)n * 3 + k] = ddpm_step(a.x[(size_t)n * 3 + k], o[k], o[3 + k], a.coef,
-                                           a.noise[(size_t)n * 3 + k], a.x_start ? a.x_start + (size_t)n * 3 + k : nullptr);
+    if (l < 3) {                                        // lane k updates component k
+        const float eps = l == 0 ? o[0] : (l == 1 ? o[1] : o[2]);
+        const float vv = l == 0 ? o[3] : (l == 1 ? o[4] : o[5]);
+        const size_t i = (size_t)n * 3 + l;
+        a.x[i] = ddpm_step(a.x[i], eps, vv, a.coef, a.noise[i], a.x_start ? a.x_start + i : nullptr);
+    }
 }
 
 // stand-alone DDPM update on a model output [n][6]
@@ -780,7 +688,7 @@ static inline int mods_offset(int head) {  // enc0..2, dec0..2, final
 
 static int g_num_cu = 0;
 
-static int num_cu() {
+int num_cu() {
     if (!g_num_cu) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -796,7 +704,7 @@ static int num_cu() {
 // launch that follows would then fail with a less telling error, so the failure is kept for
 // codlad_check_launch to report.
 static hipError_t g_attr_error = hipSuccess;
-static void set_max_lds(const void *fn, size_t bytes) {
+void set_max_lds(const void *fn, size_t bytes) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess && g_attr_error == hipSuccess) g_attr_error = e;
 }
@@ -806,8 +714,11 @@ hipError_t codlad_take_attr_error() {
     return e;
 }
 
+// edge_tile_kernels.hip
+void launch_edge_tile(int terms, bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st);
+
 template <int TERMS>
-static void launch_edge_h(bool update, const EdgeArgs &ea, hipStream_t st) {
+static void launch_edge_h(bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st) {
     static bool attr_set = false;     // one flag per TERMS instantiation
     constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
     const size_t lds_msg = 16 * edge_lds_u4<false, MSG_WAVES>(), lds_upd = 16 * edge_lds_u4<true, UPD_WAVES>();
@@ -824,18 +735,20 @@ static void launch_edge_h(bool update, const EdgeArgs &ea, hipStream_t st) {
         attr_set = true;
     }
     const int nw = update ? UPD_WAVES : MSG_WAVES;
+    const bool hoisted = ea.E1 != nullptr;
+    if (tile_list) return launch_edge_tile(TERMS, update, ea, tile_list, n_tiles, st);
     const int groups = (ea.n_nodes + nw - 1) / nw;
     dim3 grid(groups < num_cu() ? groups : num_cu()), block(nw * 64);
-    const bool hoisted = ea.E1 != nullptr;
     if (update && hoisted) hipLaunchKernelGGL((upd_kernel_h<UPD_WAVES, true, TERMS>), grid, block, lds_upd, st, ea);
     else if (update) hipLaunchKernelGGL((upd_kernel_h<UPD_WAVES, false, TERMS>), grid, block, lds_upd, st, ea);
     else if (hoisted) hipLaunchKernelGGL((msg_kernel_h<MSG_WAVES, true, TERMS>), grid, block, lds_msg, st, ea);
     else hipLaunchKernelGGL((msg_kernel_h<MSG_WAVES, false, TERMS>), grid, block, lds_msg, st, ea);
 }
 
-static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st) {
-    if (precision == 2) return launch_edge_h<3>(update, ea, st);
-    if (precision == 1) return launch_edge_h<4>(update, ea, st);
+static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st, const int2 *tile_list = nullptr,
+                        int n_tiles = 0) {
+    if (precision == 2) return launch_edge_h<3>(update, ea, tile_list, n_tiles, st);
+    if (precision == 1) return launch_edge_h<4>(update, ea, tile_list, n_tiles, st);
     dim3 grid((ea.n_nodes + 3) / 4), block(256);
     if (update) hipLaunchKernelGGL(edge_kernel<true>, grid, block, 0, st, ea);
     else hipLaunchKernelGGL(edge_kernel<false>, grid, block, 0, st, ea);
@@ -862,9 +775,31 @@ static void launch_node_hw(bool upd, const NodeArgs &na, hipStream_t st) {
     else hipLaunchKernelGGL((node_kernel_h<false, NW, TERMS>), grid, block, lds, st, na);
 }
 
+// Jobs of up to CODLAD_NODEQ_MAX_TILES 32-node tiles take the quarter kernel (one tile per 4-wave workgroup).
+static int g_options[CODLAD_N_OPTIONS] = {-1, -1, -1, -1};
+static int option_or(int opt, const char *env, int dflt) {
+    if (g_options[opt] < 0) {
+        const char *e = getenv(env);
+        g_options[opt] = e ? atoi(e) : dflt;
+    }
+    return g_options[opt];
+}
+extern "C" int codlad_set_option(int option, int value) {
+    CODLAD_REQUIRE(option >= 0 && option < CODLAD_N_OPTIONS && value >= 0, "unknown option or negative value");
+    g_options[option] = value;
+    return 0;
+}
+static int edge_tile_max_nodes() { return option_or(CODLAD_OPT_EDGE_TILE_MAX_NODES, "CODLAD_EDGE_TILE_MAX_NODES", 1 << 30); }
+static int nodeq_max_tiles() { return option_or(CODLAD_OPT_NODEQ_MAX_TILES, "CODLAD_NODEQ_MAX_TILES", 256); }
+
+// node_wide_kernels.hip
+void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st);
+
 template <int TERMS>
 static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
-    if ((na.n_nodes + 31) / 32 > 4 * num_cu()) launch_node_hw<TERMS, 8>(upd, na, st);
+    const int tiles = (na.n_nodes + 31) / 32;
+    if (tiles <= nodeq_max_tiles()) launch_node_wide(TERMS, upd, na, st);
+    else if (tiles > 4 * num_cu()) launch_node_hw<TERMS, 8>(upd, na, st);
     else launch_node_hw<TERMS, 4>(upd, na, st);
 }
 
@@ -909,6 +844,11 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
     const size_t NS = (size_t)n_nodes * HD;
     float *PQ0 = ws->PQ, *PQ1 = ws->PQ + NS, *PQ2 = ws->PQ + 2 * NS, *PQ3 = ws->PQ + 3 * NS;
     const bool split = w->precision != 0;
+    // small jobs: edge kernels per 32-edge tile, message sums per half (S[2][n_nodes][128])
+    // (while every wave of the persistent grid gets at most one tile: beyond that the per-node order is as good)
+    const bool tilewise = split && ws->tile_list && ws->n_tiles > 0 && ws->n_tiles <= 8 * num_cu() &&
+                          n_nodes <= edge_tile_max_nodes();
+    const int2 *tile_list = tilewise ? reinterpret_cast<const int2 *>(ws->tile_list) : nullptr;
 
     // h_V = x_in(x); P/Q for encoder layer 0's message
     {
@@ -934,7 +874,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         ea.W1h = Lh.W1e; ea.W2h = Lh.W2;
         set_msg_scales(ea, split, L.b2, Lh.b2, Lh.e1, Lh.e2);
         if (l == 0 && E1) ea.E1 = E1;
-        launch_edge(false, ea, w->precision, st);
+        launch_edge(false, ea, w->precision, st, tile_list, ws->n_tiles);
 
         NodeArgs na = {};
         na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
@@ -942,6 +882,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         for (int c = 0; c < 4; ++c) { na.Win[c] = L.Win[c]; na.Wout[c] = L.Wout[c]; }
         na.b_in = split ? Lh.b_in : L.b_in; na.b_out = split ? Lh.b_out : L.b_out;
         set_node_scales(na, split, Lh.e1 + Lh.e2, Lh.e3, Lh.e_in, Lh.e_out);
+        na.s_partials = tilewise;
         na.n_proj = 4;
         na.proj_w[0] = L.W11a; na.proj_b[0] = split ? Lh.b11 : L.b11; na.proj_out[0] = PQ2;   // edge update P
         na.proj_w[1] = L.W11c; na.proj_b[1] = nullptr;                 na.proj_out[1] = PQ3;   // edge update Q
@@ -973,7 +914,7 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         eu.W1h = Lh.W11e; eu.W2h = Lh.W12; eu.W3h = Lh.W13;
         set_upd_scales(eu, split, L, Lh);
         if (l == 0 && E1) eu.E1 = E1 + n_snodes * 64 * HD;
-        launch_edge(true, eu, w->precision, st);
+        launch_edge(true, eu, w->precision, st, tile_list, ws->n_tiles);
     }
     for (int l = 0; l < 3; ++l) {
         const codlad_dec_layer &L = w->dec[l];
@@ -984,10 +925,10 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
         ea.P = PQ0; ea.Q = PQ1; ea.W1 = L.W1e; ea.W2 = L.W2; ea.S = ws->S;
         ea.W1h = Lh.W1e; ea.W2h = Lh.W2;
         set_msg_scales(ea, split, L.b2, Lh.b2, Lh.e1, Lh.e2);
-        launch_edge(false, ea, w->precision, st);
+        launch_edge(false, ea, w->precision, st, tile_list, ws->n_tiles);
 
         NodeArgs na = {};
-        na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV;
+        na.node_info = ni; na.n_nodes = n_nodes; na.S = ws->S; na.hV = ws->hV; na.s_partials = tilewise;
         na.W3 = L.W3; na.b3 = split ? Lh.b3 : L.b3; na.mods = mods_t + mods_offset(3 + l);
         for (int c = 0; c < 4; ++c) { na.Win[c] = L.Win[c]; na.Wout[c] = L.Wout[c]; }
         na.b_in = split ? Lh.b_in : L.b_in; na.b_out = split ? Lh.b_out : L.b_out;
@@ -1034,7 +975,7 @@ extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const i
     FinalArgs fa = {};
     fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
     fa.n_nodes = n_nodes; fa.logits = out; fa.status = ws->status;
-    hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 7) / 8), dim3(256), 0, st, fa);
     return codlad_check_launch("codlad_denoiser_forward");
 }
 
@@ -1072,7 +1013,7 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
         fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
         fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
         fa.coef = coef + (size_t)i * 8; fa.x_start = x_start; fa.status = ws->status;
-        hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 7) / 8), dim3(256), 0, st, fa);
     }
     return codlad_check_launch("codlad_sample_loop");
 }

@@ -1,0 +1,351 @@
+// Split-fp16 node update for SMALL and medium jobs ("wide" kernel), its own translation unit (see edge_args.h).
+//
+// node_kernel_h (denoiser_kernels.hip) gives a 32-node tile to ONE wave, which walks the up to 13 weight blocks of
+// the update one after the other: right when thousands of tiles share every block through LDS, but a job of a
+// few hundred nodes then keeps a handful of waves busy for 13 dependent block fetches (46 us per launch at 87
+// nodes: half of a DDPM step).  Here a workgroup of EIGHT waves (g, bo), g in {0, 1}, owns one tile:
+//   * every contraction is cut by output block: a wave computes the 32 output features 32 bo .. 32 bo + 31 - 8
+//     k-steps x TERMS MFMAs - with its 16 KB of weight fragments loaded straight from L2 into registers, two
+//     blocks ahead of use;
+//   * independent contractions run side by side: the four W_in chunks of the FFN and the up to four projections
+//     two at a time (g and g + 2); the four W_out chunks accumulate onto one accumulator and stay a chain on the
+//     waves g = 0 (keeping the summation order of the one-wave kernel), but a short one: their GELU-ed, split
+//     inputs are already waiting in LDS;
+//   * operands travel between waves as split-fp16 FRAGMENTS (16 KB per tile in LDS): the wave that owns output
+//     block b holds exactly the registers that make up the fragments of k-steps 2b and 2b + 1, so every element is
+//     activated and split once, by its producer; LayerNorm / modulation need whole columns and run on the waves
+//     g = 0, each on the full tile (exchanged as fp32 through LDS), with the code of the one-wave kernel.
+// Same arithmetic in the same order per element and per accumulator => results are bit-identical to
+// node_kernel_h (tests/test_hip_parity.py).  Critical path: W3 | LN | 2 x W_in | 4 x W_out | LN | 2 projections = 9
+// short contractions of 24 MFMAs instead of 13 of 96.
+#include "node_args.h"
+
+namespace {
+
+constexpr int WIDE_WAVES = 8;
+constexpr int FRAG_U4 = 1024;                        // one tile as fragments: [8 k-steps][hi, lo][64 lanes] x 16 B
+// LDS map in 16-byte words
+constexpr int L_FRAG_A = 0;                          // input fragments of the current phase (S, v, projection input)
+constexpr int L_FRAG_B = L_FRAG_A + FRAG_U4;         // projection input h_V + h_Venc
+constexpr int L_HID = L_FRAG_B + FRAG_U4;            // 4 hidden tiles of the FFN, GELU-ed, as fragments
+constexpr int L_XCH = L_HID + 4 * FRAG_U4;           // one fp32 tile [32 chunks][32 columns] float4
+constexpr int L_MOD = L_XCH + 1024;                  // folded modulation vectors A1, B1, A2, B2
+constexpr int L_VEC = L_MOD + 128;                   // b3, b_in[4], b_out, projection biases [4] (128 floats each)
+constexpr int L_END = L_VEC + 10 * 32;
+constexpr int WIDE_LDS_BYTES = L_END * 16;
+
+struct BlockQuarter {                                // the weight fragments of one output block of one 128x128 block
+    u32x4 w[8][2];
+    DEV void start(const void *Wpacked, int bo, int lane) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wpacked), 0, 65536, 0x00020000);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            w[ks][0] = weight_frag_load(rsrc, lane, (ks * 4 + bo) * 2 + 0);
+            w[ks][1] = weight_frag_load(rsrc, lane, (ks * 4 + bo) * 2 + 1);
+        }
+    }
+    // acc += W[32 bo .. 32 bo + 31][:] @ tile, the tile read as fragments from LDS
+    template <int TERMS>
+    DEV void run(f32x16 &acc, const u32x4 *frag, int lane) const {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            SplitFrag x;
+            x.hi = as_f16x8(frag[(ks * 2 + 0) * 64 + lane]);
+            x.lo = as_f16x8(frag[(ks * 2 + 1) * 64 + lane]);
+            mfma_f16<TERMS>(acc, as_f16x8(w[ks][0]), as_f16x8(w[ks][1]), x);
+        }
+    }
+};
+
+// The 16 registers of output block `bo` ARE the elements of the fragments of k-steps 2 bo and 2 bo + 1 (register
+// 8 s + j = element j of k-step 2 bo + s): activate (optionally), split, write both fragments.
+template <bool GELU>
+DEV void publish_quarter(u32x4 *frag, f32x16 q, int bo, int lane, const GeluK &gk) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        SplitFrag f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x2 x = {q[8 * s + 2 * p], q[8 * s + 2 * p + 1]};
+            if (GELU) {
+                f32x2 t[1] = {x};
+                gelu_pairs<1>(t, gk);
+                x = t[0];
+            }
+            const f16x2 hh = __builtin_convertvector(x, f16x2);
+            const f16x2 ll = split_lo_pair(hh, x);
+            f.hi[2 * p] = hh.x; f.hi[2 * p + 1] = hh.y;
+            f.lo[2 * p] = ll.x; f.lo[2 * p + 1] = ll.y;
+        }
+        frag[((2 * bo + s) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, f.hi);
+        frag[((2 * bo + s) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, f.lo);
+    }
+}
+
+DEV void quarter_load(f32x16 &a, const float *row, int bo, int h) {     // this wave's block of a 128-float vector
+    const float4 *p = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = p[8 * bo + 2 * q + h];
+        a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+}
+DEV void quarter_store(const f32x16 &a, float *row, int bo, int h) {
+    float4 *p = reinterpret_cast<float4 *>(row);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[8 * bo + 2 * q + h] = make_float4(a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+DEV f32x16 quarter_of(const Tile &t, int bo) {       // bo is wave-uniform
+    return bo == 0 ? t.b[0] : (bo == 1 ? t.b[1] : (bo == 2 ? t.b[2] : t.b[3]));
+}
+DEV void xch_write(float4 *buf, const f32x16 &a, int bo, int h, int c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) buf[(8 * bo + 2 * q + h) * 32 + c] = make_float4(a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+DEV void xch_read(Tile &t, const float4 *buf, int h, int c) {
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = buf[(8 * bo + 2 * q + h) * 32 + c];
+            t.b[bo][4 * q + 0] = v.x; t.b[bo][4 * q + 1] = v.y; t.b[bo][4 * q + 2] = v.z; t.b[bo][4 * q + 3] = v.w;
+        }
+}
+
+template <bool MODE_UPD, int TERMS>
+__global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) {
+    extern __shared__ __align__(16) u32x4 wl[];
+    u32x4 *fragA = wl + L_FRAG_A, *fragB = wl + L_FRAG_B;
+    float4 *xch = reinterpret_cast<float4 *>(wl + L_XCH);
+    const float *modAB = reinterpret_cast<const float *>(wl + L_MOD);
+    const float *lv = reinterpret_cast<const float *>(wl + L_VEC);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave >> 2, bo = wave & 3;                  // g in {0, 1}: which contraction of a round; output block
+    const int h = lane >> 5, c = lane & 31;
+    const int node = blockIdx.x * 32 + c;
+    const bool valid = node < a.n_nodes;
+    const int nc = valid ? node : a.n_nodes - 1;
+    const int4 info = a.node_info[nc];
+    const bool lead = g == 0;                                // the four waves that own the tile's columns
+    const GeluK plain = gelu_consts(0);
+
+    // Every wave works through a fixed list of blocks with two fragment buffers: the block after next is
+    // requested as soon as a buffer has been consumed (lead waves hold that request back across a LayerNorm,
+    // where they need the registers).
+    //   lead, update : W3, W_in 0, W_in 2, W_out 0, W_out 1, W_out 2, W_out 3, projection 0, projection 2
+    //   other, update: W_in 1, W_in 3, projection 1, projection 3
+    //   input kernel : projection g, projection g + 2
+    BlockQuarter w0, w1;
+    auto proj_blk = [&](int p) { return a.blk_h[(MODE_UPD ? 9 : 0) + p]; };
+    if (MODE_UPD) {
+        if (lead) {
+            w0.start(a.blk_h[0], bo, lane);                  // W3
+            w1.start(a.blk_h[1], bo, lane);                  // W_in 0
+        } else {
+            w0.start(a.blk_h[3], bo, lane);                  // W_in 1
+            w1.start(a.blk_h[7], bo, lane);                  // W_in 3
+        }
+    } else {
+        if (g < a.n_proj) w0.start(proj_blk(g), bo, lane);
+        if (g + 2 < a.n_proj) w1.start(proj_blk(g + 2), bo, lane);
+    }
+    // the tile's own rows (lead waves), requested before anything is waited for
+    Tile v;
+    f32x16 sq;
+    if (MODE_UPD && lead) {
+        quarter_load(sq, a.S + (size_t)nc * HD, bo, h);
+        if (a.s_partials) {       // tile kernels: one partial per half and lane half, planes half + 2 h; same order as msg_kernel_h
+            const size_t plane = (size_t)a.n_nodes * HD;
+            f32x16 s1, s2, s3;
+            quarter_load(s2, a.S + 2 * plane + (size_t)nc * HD, bo, h);
+            if (info.z > 32) {
+                quarter_load(s1, a.S + plane + (size_t)nc * HD, bo, h);
+                quarter_load(s3, a.S + 3 * plane + (size_t)nc * HD, bo, h);
+                sq = (sq + s1) + (s2 + s3);
+            } else {
+                sq = sq + s2;
+            }
+        }
+        tile_load_row(v, a.hV + (size_t)nc * HD, h);
+    }
+    {   // small vectors -> LDS: slot 0 b3, 1-4 b_in, 5 b_out, 6-9 projection biases (zeros where absent)
+        const int i = tid & 31;
+        for (int sl = tid >> 5; sl < 10; sl += WIDE_WAVES * 2) {
+            const float *src = nullptr;
+            if (MODE_UPD && sl == 0) src = a.b3;
+            else if (MODE_UPD && sl >= 1 && sl <= 4) src = a.b_in + (sl - 1) * HD;
+            else if (MODE_UPD && sl == 5) src = a.b_out;
+            else if (sl >= 6 && sl - 6 < a.n_proj) src = a.proj_b[sl - 6];
+            wl[L_VEC + sl * 32 + i] = src ? reinterpret_cast<const u32x4 *>(src)[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    if (MODE_UPD && tid < 64) {
+        const float4 *m = reinterpret_cast<const float4 *>(a.mods) + 96 * (tid >> 5);
+        const int i = tid & 31;
+        const float4 sv = m[i], cc = m[32 + i], gg = m[64 + i];
+        float4 *cf = reinterpret_cast<float4 *>(wl + L_MOD) + 64 * (tid >> 5);
+        cf[i] = make_float4(gg.x * (1.0f + cc.x), gg.y * (1.0f + cc.y), gg.z * (1.0f + cc.z), gg.w * (1.0f + cc.w));
+        cf[32 + i] = make_float4(gg.x * sv.x, gg.y * sv.y, gg.z * sv.z, gg.w * sv.w);
+    }
+
+    if (MODE_UPD) {
+        // ---- phase A: t = W3 @ (S / 64) + K b3 / 64, v = LN1(h_V + 64 t / 30) ------------------------------
+        if (lead) {
+            sq *= a.s_scale;
+            publish_quarter<false>(fragA, sq, bo, lane, plain);
+        }
+        __syncthreads();                                     // S fragments, staged vectors, modAB
+        if (lead) {
+            f32x16 q;
+            quarter_load(q, lv, bo, h);
+            q *= (float)info.z * 0.015625f;
+            w0.run<TERMS>(q, fragA, lane);                   // W3
+            xch_write(xch, q, bo, h, c);
+        }
+        __syncthreads();
+        if (lead) {
+            Tile t;
+            xch_read(t, xch, h, c);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v.b[b][r] += (t.b[b][r] * a.t_scale) / 30.0f;
+            tile_layernorm_affine(v, 1e-6f, modAB, modAB + HD, h);
+            publish_quarter<false>(fragA, quarter_of(v, bo), bo, lane, plain);
+            w0.start(a.blk_h[5], bo, lane);                  // W_in 2 (after the LayerNorm: registers)
+        }
+        __syncthreads();
+        // ---- phase B1: hidden chunk = GELU(W_in[chunk] @ v + b_in[chunk]); chunks g and g + 2 ----------------
+        {
+            f32x16 q;
+            quarter_load(q, lv + (1 + g) * HD, bo, h);
+            if (lead) {
+                w1.run<TERMS>(q, fragA, lane);               // W_in 0
+                w1.start(a.blk_h[2], bo, lane);              // W_out 0
+            } else {
+                w0.run<TERMS>(q, fragA, lane);               // W_in 1
+                if (1 < a.n_proj) w0.start(proj_blk(1), bo, lane);
+            }
+            publish_quarter<true>(wl + L_HID + g * FRAG_U4, q, bo, lane, a.gelu_ffn);
+            quarter_load(q, lv + (3 + g) * HD, bo, h);
+            if (lead) {
+                w0.run<TERMS>(q, fragA, lane);               // W_in 2
+                w0.start(a.blk_h[4], bo, lane);              // W_out 1
+            } else {
+                w1.run<TERMS>(q, fragA, lane);               // W_in 3
+                if (3 < a.n_proj) w1.start(proj_blk(3), bo, lane);
+            }
+            publish_quarter<true>(wl + L_HID + (2 + g) * FRAG_U4, q, bo, lane, a.gelu_ffn);
+        }
+        __syncthreads();
+        // ---- phase B2: t = b_out + sum_ch W_out[ch] @ hidden[ch] (one accumulator, chunk after chunk) -----
+        if (lead) {
+            f32x16 q;
+            quarter_load(q, lv + 5 * HD, bo, h);
+            w1.run<TERMS>(q, wl + L_HID + 0 * FRAG_U4, lane);
+            w1.start(a.blk_h[6], bo, lane);                  // W_out 2
+            w0.run<TERMS>(q, wl + L_HID + 1 * FRAG_U4, lane);
+            w0.start(a.blk_h[8], bo, lane);                  // W_out 3
+            w1.run<TERMS>(q, wl + L_HID + 2 * FRAG_U4, lane);
+            if (0 < a.n_proj) w1.start(proj_blk(0), bo, lane);
+            w0.run<TERMS>(q, wl + L_HID + 3 * FRAG_U4, lane);
+            xch_write(xch, q, bo, h, c);
+        }
+        __syncthreads();
+        if (lead) {
+            Tile t;
+            xch_read(t, xch, h, c);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v.b[b] += t.b[b] * a.ffn_scale;
+            tile_layernorm_affine(v, 1e-6f, modAB + 2 * HD, modAB + 3 * HD, h);
+            if (2 < a.n_proj) w0.start(proj_blk(2), bo, lane);
+        }
+    } else {
+        __syncthreads();                                     // staged vectors
+    }
+    // ---- new h_V: store, publish the projection inputs ----------------------------------------------------
+    bool any_sum = false;
+    for (int p = 0; p < a.n_proj; ++p) any_sum |= (a.proj_flags[p] & 1) != 0;
+    if (lead) {
+        f32x16 mine;
+        if (MODE_UPD) {
+            if (valid && bo == 0) {
+                tile_store_row(v, a.hV + (size_t)node * HD, h);
+                if (a.hVenc_out) tile_store_row(v, a.hVenc_out + (size_t)node * HD, h);
+            }
+            mine = quarter_of(v, bo);
+        } else {
+            // h_V = x_in(x) is element-wise per feature: every lead wave computes and stores its own block only
+            const float x0 = a.x[nc * 3 + 0], x1 = a.x[nc * 3 + 1], x2 = a.x[nc * 3 + 2];
+            const bool sc = a.in_dim == 6;
+            const bool have_sc = sc && a.x_sc != nullptr;
+            const float s0 = have_sc ? a.x_sc[nc * 3 + 0] : 0.f, s1 = have_sc ? a.x_sc[nc * 3 + 1] : 0.f,
+                        s2 = have_sc ? a.x_sc[nc * 3 + 2] : 0.f;
+            quarter_load(mine, a.x_in_b, bo, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * bo + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float *wr = a.x_in_w + f * a.in_dim;
+                float acc = 0.f;
+                if (sc) {
+                    acc = fmaf(s2, wr[2], fmaf(s1, wr[1], s0 * wr[0]));
+                    wr += 3;
+                }
+                mine[r] += fmaf(x2, wr[2], fmaf(x1, wr[1], fmaf(x0, wr[0], acc)));
+            }
+            if (valid) {
+                quarter_store(mine, a.hV + (size_t)node * HD, bo, h);
+                if (a.hVenc_out) quarter_store(mine, a.hVenc_out + (size_t)node * HD, bo, h);
+            }
+        }
+        publish_quarter<false>(fragA, mine, bo, lane, plain);
+        if (any_sum) {
+            f32x16 sum = mine;
+            if (a.venc_is_self) {
+                sum += mine;
+            } else {
+                f32x16 e;
+                quarter_load(e, a.hVenc_in + (size_t)nc * HD, bo, h);
+                sum += e;
+            }
+            publish_quarter<false>(fragB, sum, bo, lane, plain);
+        }
+    }
+    __syncthreads();
+    // ---- phase C: projections g and g + 2 on the waves (g, bo) ----------------------------------------------
+    auto project = [&](int p, const BlockQuarter &wp) {
+        const int fl = a.proj_flags[p];
+        f32x16 out;
+        quarter_load(out, lv + (6 + p) * HD, bo, h);
+        if (fl & 2) {
+            f32x16 ts;
+            quarter_load(ts, a.TS + (size_t)info.w * HD, bo, h);
+            out += ts;
+        }
+        wp.run<TERMS>(out, (fl & 1) ? fragB : fragA, lane);
+        if (valid) quarter_store(out, a.proj_out[p] + (size_t)node * HD, bo, h);
+    };
+    // buffers: input kernel w0 / w1; update kernel: lead w1 (projection 0) / w0 (projection 2), others w0 / w1
+    if (g < a.n_proj) project(g, (MODE_UPD && lead) ? w1 : w0);
+    if (g + 2 < a.n_proj) project(g + 2, (MODE_UPD && lead) ? w0 : w1);
+}
+
+template <int TERMS>
+void launch_w(bool upd, const NodeArgs &na, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_max_lds(reinterpret_cast<const void *>(node_kernel_w<true, TERMS>), WIDE_LDS_BYTES);
+        set_max_lds(reinterpret_cast<const void *>(node_kernel_w<false, TERMS>), WIDE_LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((na.n_nodes + 31) / 32), block(WIDE_WAVES * 64);
+    if (upd) hipLaunchKernelGGL((node_kernel_w<true, TERMS>), grid, block, WIDE_LDS_BYTES, st, na);
+    else hipLaunchKernelGGL((node_kernel_w<false, TERMS>), grid, block, WIDE_LDS_BYTES, st, na);
+}
+
+}  // namespace
+
+void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st) {
+    if (terms == 3) launch_w<3>(upd, na, st);
+    else launch_w<4>(upd, na, st);
+}

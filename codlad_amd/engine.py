@@ -78,17 +78,25 @@ class Job:
         f32 = dict(dtype=torch.float32, device=device)
         self.hV = torch.empty(n, H, **f32)
         self.hVenc = torch.empty(n, H, **f32)
-        self.S = torch.empty(n, H, **f32)
+        self.S = torch.empty(4, n, H, **f32)      # planes 1-3: per-half, per-lane-half partial sums of small jobs
         self.PQ = torch.empty(4, n, H, **f32)
         self.hE = torch.empty(n, KNN, H, **f32)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)   # sticky flags (CODLAD_STATUS_*)
+        # non-empty 32-edge tiles {node, half}: small jobs deal the edge kernels' work out per tile
+        halves = np.where(info[:, 2] > 32, 2, 1)
+        tiles = np.empty((int(halves.sum()), 2), dtype=np.int32)
+        tiles[:, 0] = np.repeat(np.arange(n, dtype=np.int32), halves)
+        first = np.cumsum(halves) - halves
+        tiles[:, 1] = np.arange(tiles.shape[0], dtype=np.int32) - np.repeat(first, halves).astype(np.int32)
+        self.tile_list = torch.from_numpy(tiles).to(device)
         ws = _lib.Workspace()
-        ws.hV, ws.hVenc, ws.S, ws.PQ, ws.hE, ws.status = (
-            _lib.ptr(t) for t in (self.hV, self.hVenc, self.S, self.PQ, self.hE, self.status))
+        ws.hV, ws.hVenc, ws.S, ws.PQ, ws.hE, ws.status, ws.tile_list = (
+            _lib.ptr(t) for t in (self.hV, self.hVenc, self.S, self.PQ, self.hE, self.status, self.tile_list))
+        ws.n_tiles = tiles.shape[0]
         self.ws = ws
 
     def workspace_bytes(self):
-        return 4 * (self.hV.numel() * 3 + self.PQ.numel() + self.hE.numel())
+        return 4 * (self.hV.numel() * 2 + self.S.numel() + self.PQ.numel() + self.hE.numel())
 
 
 class Denoiser:

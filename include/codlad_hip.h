@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 5
+#define CODLAD_ABI_VERSION 6
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -157,11 +157,17 @@ int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t *t_values, 
 typedef struct {
     float *hV;      /* [n_nodes][128]                 */
     float *hVenc;   /* [n_nodes][128]                 */
-    float *S;       /* [n_nodes][128]                 */
+    float *S;       /* [4][n_nodes][128]: neighbour sums (planes 1-3: partial sums of the small-job kernels) */
     float *PQ;      /* [4][n_nodes][128]              */
     float *hE;      /* [n_nodes] edge blocks (64 x 128) */
     int32_t *status; /* [1] sticky status word (CODLAD_STATUS_*), may be NULL: set by the kernels, never
                       * cleared by them; read and cleared by codlad_status_check                       */
+    /* optional (NULL, 0 = none): the job's non-empty 32-edge tiles {node, half}, node-major - half 1 listed
+     * only for nodes with K > 32.  Small jobs (CODLAD_OPT_EDGE_TILE_MAX_NODES) deal the edge kernels' work out
+     * per tile with it, which doubles the number of busy waves; results are bit-identical to the per-node
+     * order (the partial neighbour sums are kept apart and added in that order). */
+    const int32_t *tile_list;
+    int32_t n_tiles;
 } codlad_workspace;
 
 /* Status bits.  NONFINITE: a denoiser output (eps | variance logits) was inf or NaN.  In the split-fp16
@@ -257,6 +263,19 @@ int codlad_cg_graph(const float *cg_xyz, const int32_t *sample_range, int M, flo
 int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *orders,
                      const int32_t *slot_to_out, int B, int L, int n_atoms, float *xyz_out,
                      void *stream);
+
+/* Tuning switches (speed only: every setting computes the same values).  Defaults suit MI355X; the environment
+ * variable of the same name (CODLAD_ prefix, upper case) sets the initial value.
+ *   CODLAD_OPT_NODEQ_MAX_TILES   jobs of up to this many 32-node tiles run the node update on the small-job
+ *                                "quarter" kernel (one tile per 4-wave workgroup), larger ones on the streaming one
+ *   CODLAD_OPT_EDGE_TILE_MAX_NODES  jobs of up to this many nodes deal the edge kernels' work out per 32-edge
+ *                                tile instead of per node (twice the waves for the same work)
+ *   CODLAD_OPT_LOOP_GRAPH_MAX_NODES  reserved */
+#define CODLAD_OPT_NODEQ_MAX_TILES 0
+#define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
+#define CODLAD_OPT_LOOP_GRAPH_MAX_NODES 2
+#define CODLAD_N_OPTIONS 4
+int codlad_set_option(int option, int value);
 
 /* Measurement hook: ONE launch of the message kernel (which = 0) or the edge-update kernel
  * (which = 1) of encoder layer `layer` (0 or 1) on a job whose workspace holds the state of a

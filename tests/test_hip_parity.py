@@ -478,3 +478,63 @@ def test_random_ragged_jobs_against_oracle_and_between_modes(sd):
             assert rel_err(outs["f16x3"][a:b], ref[0]) < 1e-5, (trial, k, lens[s])
             alone = d3.forward(d3.make_job(d3.prepare_structures([xyz[s]], [zz[s]]), [0]), x[a:b], t)
             assert torch.equal(alone, outs["f16x3"][a:b])
+
+
+def test_small_job_node_kernel_is_bit_identical_to_the_streaming_one(sd):
+    """The wide node kernel (small jobs: one 32-node tile per 8-wave workgroup, contractions cut by output block,
+    operands exchanged as split fragments through LDS) computes exactly what the streaming kernel does: same
+    per-element code, same accumulation order."""
+    outs = []
+    for max_tiles in (0, 1 << 20):
+        _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, max_tiles)
+        try:
+            d = Denoiser(sd, DEV, precision="f16x3")
+            pa, pb = synth.make_protein(40, 5, n_frames=1), synth.make_protein(87, 6, n_frames=1)
+            st = d.prepare_structures([torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in (pa, pb)],
+                                      [torch.from_numpy(p["z_full"])[1:-1] for p in (pa, pb)])
+            job = d.make_job(st, [0, 1, 1])
+            x = synth.gaussian((40 + 87 + 87, 3), 99).to(DEV)
+            T = 5
+            eps = synth.gaussian((T, 214, 3), 98).to(DEV)
+            outs.append((d.forward(job, x, 700), d.sample(job, x, eps, tables(T))))
+        finally:
+            _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, 256)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
+    """Small jobs deal the edge kernels' work out per non-empty 32-edge tile (two waves per node with K > 32; the
+    message sum is kept per half and lane half and added up by the node kernel in the per-node kernel's order):
+    bit-identical to the per-node order, on lengths that give empty, partial and full second halves, in both node
+    kernels, and equal to the oracle."""
+    lens = [5, 31, 32, 33, 47, 64, 87]
+    prots = [synth.make_protein(L, 300 + i, n_frames=1) for i, L in enumerate(lens)]
+    xyz = [torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in prots]
+    zz = [torch.from_numpy(p["z_full"])[1:-1] for p in prots]
+    x = synth.gaussian((sum(lens), 3), 17).to(DEV)
+    T = 4
+    eps = synth.gaussian((T, sum(lens), 3), 18).to(DEV)
+    outs = []
+    for max_nodes, wide_tiles in ((0, 256), (1 << 20, 256), (1 << 20, 0)):
+        _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, max_nodes)
+        _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, wide_tiles)
+        try:
+            d = Denoiser(sd, DEV, precision="f16x3")
+            job = d.make_job(d.prepare_structures(xyz, zz), list(range(len(lens))))
+            if max_nodes:
+                tl = job.tile_list.cpu()
+                want = [(n, hf) for n in range(sum(lens)) for hf in range(2 if int(job.node_info[n, 2]) > 32 else 1)]
+                assert [tuple(r) for r in tl.tolist()] == want
+            outs.append((d.forward(job, x, 600), d.sample(job, x, eps, tables(T))))
+        finally:
+            _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, 1 << 30)
+            _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, 256)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for k in (0, 3, 6):
+        batch = synth.make_batch(prots[k])
+        cg_z, cg_xyz, m = oden.batch_to_dense(batch)
+        a, b = int(off[k]), int(off[k + 1])
+        ref = oden.forward(sd, x[a:b].cpu()[None], torch.tensor([600]), cg_xyz, cg_z, m)
+        assert rel_err(outs[1][0][a:b], ref[0]) < 1e-5

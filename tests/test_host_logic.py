@@ -268,3 +268,23 @@ def test_cli_batches_of_one_file_get_distinct_output_names():
         frames += int(batch["num_CGs"].shape[0])
     assert len(names) == len(set(names)) == 8 and frames == 400          # 4 proteins x (96 + 4) frames
     assert names[:2] == ["synthetic_L46_b00000", "synthetic_L46_b00001"]
+
+
+def test_hot_edge_kernels_keep_their_register_budget():
+    """The per-node edge kernels (88 % of a DDPM step) are written to fit the 256-register limit of two waves per SIMD
+    with at most a handful of spilled registers outside the contraction loops.  hipcc's allocation for them is
+    fragile - other kernels in the same translation unit were enough to push 20-30 registers into scratch inside the
+    loops (-9 %) - so the build records what it got (codlad_amd/csrc/kernel_resources.json) and this holds it."""
+    import json
+    from codlad_amd import build
+    build.build(force=False, verbose=False)
+    if not os.path.exists(build.RESOURCES):
+        build.build(force=True, verbose=False)
+    with open(build.RESOURCES) as f:
+        table = json.load(f)
+    budget = {"_Z12msg_kernel_hILi8ELb0ELi3EEv8EdgeArgs": 32, "_Z12msg_kernel_hILi8ELb1ELi3EEv8EdgeArgs": 32,
+              "_Z12upd_kernel_hILi8ELb0ELi3EEv8EdgeArgs": 32, "_Z12upd_kernel_hILi8ELb1ELi3EEv8EdgeArgs": 48}
+    for name, scratch in budget.items():
+        r = table[name]
+        assert r["VGPRs"] <= 256 and r["Occupancy"] == 2, (name, r)
+        assert r["ScratchSize"] <= scratch, (name, r)

@@ -1,21 +1,50 @@
-"""Latency of small jobs (launch-bound regime): 100-step loop for a few structures of L=87."""
-import sys, time, torch
+"""Latency of small jobs (the regime of one GPU's shard of cfg 3, and of cfg 1): the 100-step DDPM loop on
+1 protein of 87 residues, 1 of 300, an 8-protein shard of cfg 3 (~1.3 k nodes) and all 64 proteins of cfg 3.
+
+    python tools/small_job_latency.py [--only N] [--reps R] [--graph 0|1]
+"""
+import argparse
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, '.')
-from codlad_amd import synth
-from codlad_amd.engine import Denoiser
-from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
-sd = synth.denoiser_state_dict(1234)
-den = Denoiser(sd, "cuda:0")
+from codlad_amd import parallel, synth                                                   # noqa: E402
+from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps   # noqa: E402
+from codlad_amd.engine import Denoiser                                                    # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", type=int, default=-1)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--graph", type=int, default=-1, help="-1: library default; 0 / 1: force HIP-graph replay off / on")
+args = ap.parse_args()
+
+torch.set_grad_enabled(False)
+den = Denoiser(synth.denoiser_state_dict(1234), "cuda:0")
 tb = Tables(named_betas("linear", 1000), space_timesteps(1000, "100"))
-for B in (1, 4, 10, 40):
-    prot = synth.make_protein(87, 5, n_frames=1)
-    x = torch.from_numpy(prot["xyz_full"])[0, 1:-1]; z = torch.from_numpy(prot["z_full"])[1:-1]
-    st = den.prepare_structures([x], [z]); job = den.make_job(st, [0] * B)
-    xT = torch.randn(job.n_nodes, 3, device="cuda"); eps = torch.randn(100, job.n_nodes, 3, device="cuda")
-    den.sample(job, xT, eps, tb); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        den.sample(job, xT, eps, tb)
+cfg3 = synth.baseline_config("cfg3")["lengths"]
+shard = parallel.shard_units([parallel.unit_cost(L) for L in cfg3], 8)[0]
+CASES = [("1 protein, L=87", [87]), ("1 protein, L=300", [300]),
+         ("cfg3 shard of one GPU (1/8, LPT): %d proteins" % len(shard), [cfg3[u] for u in shard]),
+         ("cfg3, all 64 proteins", cfg3)]
+kw = {} if args.graph < 0 else {"graph": bool(args.graph)}
+for k, (label, lens) in enumerate(CASES):
+    if args.only >= 0 and k != args.only:
+        continue
+    prots = [synth.make_protein(L, 50 + i, n_frames=1) for i, L in enumerate(lens)]
+    xs = [torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in prots]
+    zs = [torch.from_numpy(p["z_full"])[1:-1] for p in prots]
+    st = den.prepare_structures(xs, zs)
+    job = den.make_job(st, list(range(len(lens))))
+    xT = torch.randn(job.n_nodes, 3, device="cuda")
+    eps = torch.randn(100, job.n_nodes, 3, device="cuda")
+    den.sample(job, xT, eps, tb, **kw)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-    print(f"B={B:3d} ensemble members of one L=87 frame: {dt*1e3:8.2f} ms per 100-step loop = {dt/100*1e6:7.1f} us/step, {B/dt:8.1f} structures/s")
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        den.sample(job, xT, eps, tb, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.reps
+    print(f"{label:48s} {job.n_nodes:6d} nodes: {dt * 1e3:8.2f} ms per 100-step loop = {dt / 100 * 1e6:7.1f} us/step, "
+          f"{len(lens) / dt:8.1f} structures/s", flush=True)
