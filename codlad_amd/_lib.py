@@ -78,6 +78,7 @@ _SIGS = {
     "codlad_abi_version": (C.c_int, []),
     "codlad_metrics_scratch_bytes": (C.c_int, []),
     "codlad_eval_metrics": (C.c_int, [C.POINTER(MetricInputs), P, P, P]),
+    "codlad_bond_graph_counts": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_float, P, P]),
     "codlad_last_error": (C.c_char_p, []),
     "codlad_struct_sizes": (None, [C.POINTER(C.c_int)]),
     "codlad_pack_block_host": (None, [P, C.c_int, C.c_float, P]),

@@ -104,7 +104,65 @@ __global__ void metrics_finish_kernel(codlad_metric_inputs in, const double *par
     out[6] = inter;                                                         // loss_inter
     out[7] = pipi;                                                          // loss_pi_pi
 }
+// Bond-graph validity (reference test.py:168-188 -> utils/protein_module.py:251-318): atoms i != j of one structure
+// are bonded when |x_i - x_j| < (r_i + r_j) * scale, r = the covalent cut-off radius of the element.  Per structure
+// the kernel counts the bonded unordered pairs of the reference coordinates, of the reconstructed ones and the
+// pairs on which the two graphs differ - over all atoms and over the heavy atoms (Z != 1) only.  Arithmetic as the
+// reference's unfused fp32 tensor ops (sum of squares over x, y, z in that order, sqrt, (r_i + r_j) * scale).
+__global__ __launch_bounds__(256) void bond_graph_kernel(const float *xyz, const float *xyz_recon, const float *radius,
+                                                         const int32_t *heavy, const int32_t *struct_ptr, float scale,
+                                                         int32_t *counts) {
+    const int s = blockIdx.x;
+    const int a0 = struct_ptr[s], n = struct_ptr[s + 1] - a0;
+    int c[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.y; i < n; i += gridDim.y) {
+        const float xi = xyz[3 * (a0 + i)], yi = xyz[3 * (a0 + i) + 1], zi = xyz[3 * (a0 + i) + 2];
+        const float ui = xyz_recon[3 * (a0 + i)], vi = xyz_recon[3 * (a0 + i) + 1], wi = xyz_recon[3 * (a0 + i) + 2];
+        const float ri = radius[a0 + i];
+        const int hi = heavy[a0 + i];
+        for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+            const float dx = xi - xyz[3 * (a0 + j)], dy = yi - xyz[3 * (a0 + j) + 1], dz = zi - xyz[3 * (a0 + j) + 2];
+            const float du = ui - xyz_recon[3 * (a0 + j)], dv = vi - xyz_recon[3 * (a0 + j) + 1],
+                        dw = wi - xyz_recon[3 * (a0 + j) + 2];
+            const float cut = (ri + radius[a0 + j]) * scale;
+            const bool ref = sqrtf((dx * dx + dy * dy) + dz * dz) < cut;
+            const bool gen = sqrtf((du * du + dv * dv) + dw * dw) < cut;
+            const int hv = hi & heavy[a0 + j];
+            c[0] += ref; c[1] += gen; c[2] += ref != gen;
+            c[3] += ref & hv; c[4] += gen & hv; c[5] += (ref != gen) & hv;
+        }
+    }
+    __shared__ int red[256];
+    for (int k = 0; k < 6; ++k) {
+        red[threadIdx.x] = c[k];
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && red[0]) atomicAdd(counts + 6 * s + k, red[0]);   // integers: order-independent
+        __syncthreads();
+    }
+}
 }  // namespace
+
+extern "C" int codlad_bond_graph_counts(const float *xyz, const float *xyz_recon, const float *radius,
+                                        const int32_t *heavy, const int32_t *struct_ptr, int n_struct, int max_atoms,
+                                        float scale, int32_t *counts, void *stream) {
+    CODLAD_REQUIRE(xyz && xyz_recon && radius && heavy && struct_ptr && counts, "null pointer");
+    CODLAD_REQUIRE(n_struct > 0 && max_atoms > 0 && scale > 0.f, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * 6 * (size_t)n_struct, st);
+    if (e != hipSuccess) {
+        codlad_set_error("codlad_bond_graph_counts: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    int by = (max_atoms + 7) / 8;
+    by = by < 1 ? 1 : (by > 512 ? 512 : by);
+    hipLaunchKernelGGL(bond_graph_kernel, dim3(n_struct, by), dim3(256), 0, st, xyz, xyz_recon, radius, heavy, struct_ptr,
+                       scale, counts);
+    return codlad_check_launch("codlad_bond_graph_counts");
+}
 
 extern "C" int codlad_metrics_scratch_bytes(void) { return MAX_BLOCKS * N_ACC * (int)sizeof(double); }
 

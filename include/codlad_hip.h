@@ -315,6 +315,16 @@ typedef struct {
 int codlad_metrics_scratch_bytes(void);
 int codlad_eval_metrics(const codlad_metric_inputs *in, float *out8, void *scratch, void *stream);
 
+/* Next row 8f-2: bond-graph validity, valid_ratio_and_cut_off_result (test.py:168-188) ->
+ * eval_sample_qualities / count_valid_graphs / get_bond_graphs (utils/protein_module.py:251-364).  Atoms are flat
+ * over structures, struct_ptr int32 [n_struct + 1] = atom offsets; radius [n_atoms] = covalent cut-off radius of
+ * each atom's element (COVCUTOFFTABLE), heavy int32 [n_atoms] = 1 for Z != 1.  counts int32 [n_struct][6] =
+ * {bonds in xyz, bonds in xyz_recon, pairs on which the graphs differ} over all atoms, then over heavy atoms
+ * (unordered pairs; the reference's full matrices count each twice, which cancels in its ratios). */
+int codlad_bond_graph_counts(const float *xyz, const float *xyz_recon, const float *radius, const int32_t *heavy,
+                             const int32_t *struct_ptr, int n_struct, int max_atoms, float scale, int32_t *counts,
+                             void *stream);
+
 /* Self-test of the MFMA chain primitive: Y[n][:] = act(W @ X[n][:] + bias), n < 32*tiles.
  * act: 0 = none, 1 = exact-erf GELU. */
 int codlad_selftest_gemm128(const float *W_packed, const float *bias, const float *X, int n_rows,

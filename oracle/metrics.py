@@ -59,3 +59,30 @@ def inter_result(interaction_list, pi_pi_list, xyz_recon):
         loss_pipi = torch.clamp(((c0 - c1).pow(2).sum(-1) + EPS).sqrt() - 6.0, min=0.0).mean()
         loss_inter = loss_inter + loss_pipi * (n_pipi / total)
     return loss_inter, loss_pipi
+
+
+def bond_graph(xyz, radius, scale=1.3):
+    """utils/protein_module.py:251-288 (compute_bond_cutoff, compute_distance_mat, get_bond_graphs): 0/1 matrix
+    of atom pairs closer than (r_i + r_j) * scale, diagonal cleared."""
+    dist = (xyz[:, None, :] - xyz[None, :, :]).pow(2).sum(-1).sqrt()
+    cutoff = (radius[None, :] + radius[:, None]) * scale
+    bonds = dist < cutoff
+    bonds[torch.arange(len(xyz)), torch.arange(len(xyz))] = False
+    return bonds.to(torch.long)
+
+
+def valid_ratio_and_cut_off_result(xyz, xyz_recon, num_atoms, atomic_nums, cov_cutoff):
+    """test.py:168-188 -> eval_sample_qualities / count_valid_graphs (utils/protein_module.py:290-364) for one
+    reconstruction per reference structure; ase.Atoms is only a container of (numbers, positions) there.
+    cov_cutoff: radius by atomic number - 1 (COVCUTOFFTABLE, protein_module.py:128-234)."""
+    hv, av, hg, ag = [], [], [], []
+    table = torch.tensor(cov_cutoff, dtype=torch.float32)
+    for x, y, z in zip(torch.split(xyz.float().cpu(), list(num_atoms)), torch.split(xyz_recon.float().cpu(), list(num_atoms)),
+                       torch.split(torch.as_tensor(atomic_nums).long(), list(num_atoms))):
+        for heavy_only, valid, ged in ((True, hv, hg), (False, av, ag)):
+            keep = z != 1 if heavy_only else torch.ones_like(z, dtype=torch.bool)
+            r = table[z[keep] - 1]
+            ref, gen = bond_graph(x[keep], r), bond_graph(y[keep], r)
+            valid.append(1.0 if int((gen != ref).sum()) == 0 else 0.0)
+            ged.append([((ref - gen).sum().abs() / ref.sum()).item()])
+    return hv, av, hg, ag

@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from codlad_amd import synth
+from codlad_amd import metrics, synth
 from codlad_amd.diffusion_and_flow import create_diffusion
 from codlad_amd.models.latent_model import MPNN_models
 from codlad_amd.utils.dataset_module import CG_collate, get_norm_feature
@@ -97,6 +97,51 @@ def iter_batches(args):
             yield output_name(os.path.basename(path), c, len(plan)), CG_collate([testset[i] for i in range(a, b)]), info
 
 
+EVAL_KEYS = ("nxyz", "num_atoms", "bond_edge_list", "nbr_list", "bb_NO_list", "interaction_list", "pi_pi_list", "ic",
+             "mask", "mask_xyz_list")
+
+
+class Evaluation:
+    """The evaluation block of the reference's loop (test.py:566-668, 707-785) on the device: per batch and ensemble
+    member the reconstruction / coordinate / bond-graph / clash / interaction losses (codlad_eval_metrics, one launch)
+    and the bond-graph validity (codlad_bond_graph_counts); per data file the summary the reference prints."""
+
+    def __init__(self):
+        self.rows, self.valid, self.ged, self.rmsd = [], [], [], []
+        self.recon, self.true = [], None
+
+    def add(self, batch, ic_recon, xyz_recon, n_atoms):
+        xyz = batch["nxyz"][:, 1:].clone()
+        xr = xyz_recon.reshape(-1, 3).clone()
+        mask_xyz = batch["mask_xyz_list"]
+        xyz[mask_xyz] *= 0                                   # test.py:585-586
+        xr[mask_xyz] *= 0
+        r = metrics.all_results(ic_recon, batch["ic"], batch["mask"], xr, xyz, batch["bond_edge_list"], batch["nbr_list"],
+                                batch["bb_NO_list"], batch["interaction_list"], batch["pi_pi_list"])
+        _hv, av, _hg, ag = metrics.valid_ratio_and_cut_off_result(xyz, xr, batch["num_atoms"], batch["nxyz"][:, 0].cpu())
+        self.rows.append({k: float(v) for k, v in r.items()})
+        self.valid += av
+        self.ged += ag
+        a, b = xr.reshape(-1, n_atoms, 3), xyz.reshape(-1, n_atoms, 3)
+        self.rmsd.append((a - b).pow(2).sum(-1).mean(-1).sqrt().mean().item())      # unaligned all-atom RMSD, test.py:661
+        self.recon.append(a.cpu())
+        self.true = b.cpu()
+
+    def report(self, name, args):
+        mean = lambda k: float(np.mean([r[k] for r in self.rows]))  # noqa: E731
+        stats = {"data_name": name, "data_type": args.data_type, "num_ensemble": args.num_ensemble,
+                 "experiment": args.experiment, "test_all_recon": float(np.mean(self.rmsd)),
+                 "test_xyz": mean("loss_xyz"), "test_graph": mean("loss_graph"), "test_nbr": mean("loss_nbr"),
+                 "test_inter": mean("loss_inter"), "test_pi_pi": mean("loss_pi_pi"),
+                 "test_all_valid_ratio": float(np.mean(self.valid)), "test_all_ged": float(np.mean(self.ged)),
+                 "diversity": metrics.compute_div(self.recon, self.true) if len(self.recon) > 1 else 0}
+        print("############## vvvvvvvvv result test_stats:")
+        for k, v in stats.items():
+            print(k, v)
+        print("############## ^^^^^^^^^ result test_stats:")
+        return stats
+
+
 def main(args):
     if not torch.cuda.is_available():
         raise SystemExit("test.py (codlad_amd) needs an MI355X: there is no CPU path")
@@ -161,13 +206,18 @@ def main(args):
         nres = L + 2
         og = batch["OG_CG_nxyz"].reshape(-1, nres, 4)
         xyz_all = []
+        evaluation = Evaluation() if all(k in batch for k in EVAL_KEYS) else None
         for e in range(E):
             _, ic_recon = vae.latent_decode(samples[e * B:(e + 1) * B], mask[:B], batch)
             xyz_all.append(ic_to_xyz(og, ic_recon.reshape(-1, nres - 2, 13, 3), info))
+            if evaluation is not None:                               # reference test.py:589-594, per ensemble member
+                evaluation.add(batch, ic_recon, xyz_all[-1], xyz_all[-1].shape[1])
         xyz = torch.stack(xyz_all)                                   # [E, B, n_atoms, 3]
         torch.cuda.synchronize()
         dt = time.time() - st
         total += B * E
+        if evaluation is not None:
+            evaluation.report(name, args)
         np.save(os.path.join(save_dir, f"{name}_xyz_recon.npy"), xyz.cpu().numpy())
         print(f"{name}: {B} frames x {E} members, L={L}, {xyz.shape[2]} atoms: {dt:.2f}s "
               f"({B * E / dt:.1f} structures/s)", flush=True)

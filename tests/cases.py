@@ -196,6 +196,33 @@ def metric_inputs(name):
                 interaction_list=t(inter), pi_pi_list=t(pipi), ic=t(ic), ic_recon=t(ic_recon), mask=t(mask))
 
 
+VALIDITY_CASES = {"tight": 0.02, "loose": 0.12, "broken": 0.45}     # name -> coordinate noise of the reconstruction (A)
+
+
+def validity_inputs(name):
+    """Inputs of the bond-graph validity metric (reference test.py:168-188): the three all-atom structures of golden
+    g6_xyz_N6_L46_B3 (what the reference's ic_to_xyz produced) as reference coordinates, a noisy copy as the
+    reconstruction, atomic numbers from the atom names of the sequence (every 9th atom relabelled hydrogen so that
+    the heavy-atom filter does something)."""
+    import numpy as np
+    import torch
+    L, B, seed, _vae = DECODER_CASES["N6_L46_B3"]
+    prot = synth.make_protein(L, seed, n_frames=B)
+    xyz = torch.from_numpy(np.load(npz_path("g6_xyz_N6_L46_B3"))["xyz"]).float()           # [B, n_atoms, 3]
+    names = [synth.IDX2THR[int(z)] for z in prot["z_full"][1:-1]]
+    elem = {"C": 6, "N": 7, "O": 8, "S": 16, "P": 15}
+    z = [elem[a[0]] for nm in names for a in synth.PDB_ATOM_ORDER[nm]]
+    assert len(z) == xyz.shape[1]
+    z = torch.tensor(z, dtype=torch.int64)
+    z[::9] = 1
+    r = np.random.Generator(np.random.PCG64(700 + len(name)))
+    recon = xyz + torch.from_numpy(r.standard_normal(tuple(xyz.shape)).astype(np.float32)) * VALIDITY_CASES[name]
+    if name == "tight":
+        recon[0] = xyz[0]                       # an exact reconstruction: valid by construction
+    return dict(xyz=xyz.reshape(-1, 3), xyz_recon=recon.reshape(-1, 3), num_atoms=torch.tensor([xyz.shape[1]] * B),
+                atomic_nums=z.repeat(B))
+
+
 def npz_path(name):
     import os
     return os.path.join(os.path.dirname(__file__), "golden", name + ".npz")

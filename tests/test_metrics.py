@@ -64,3 +64,79 @@ def test_cpu_tensors_are_refused():
     d = cases.metric_inputs("small")
     with pytest.raises(RuntimeError):
         gm.xyz_result(d["xyz_recon"].to(DEV), d["xyz"])
+
+
+@pytest.mark.parametrize("name", list(cases.VALIDITY_CASES))
+def test_bond_graph_validity_matches_reference(name):
+    """codlad_bond_graph_counts / valid_ratio_and_cut_off_result against the goldens the reference's own function
+    produced (test.py:168-188): validity flags and bond-count ratios exactly, and the raw counts against the oracle's
+    bond matrices."""
+    gold = np.load(cases.npz_path(f"g11_validity_{name}"))
+    d = cases.validity_inputs(name)
+    hv, av, hg, ag = gm.valid_ratio_and_cut_off_result(d["xyz"].to(DEV), d["xyz_recon"].to(DEV), d["num_atoms"],
+                                                       d["atomic_nums"])
+    assert hv == gold["heavy_valid"].tolist() and av == gold["all_valid"].tolist()
+    assert np.array_equal(np.array(hg, dtype=np.float64), gold["heavy_ged"])
+    assert np.array_equal(np.array(ag, dtype=np.float64), gold["all_ged"])
+    cnt = gm.bond_graph_counts(d["xyz"].to(DEV), d["xyz_recon"].to(DEV), d["num_atoms"], d["atomic_nums"]).cpu()
+    table = torch.tensor(gm.COV_CUTOFF)
+    n = int(d["num_atoms"][0])
+    for s in range(len(d["num_atoms"])):
+        z = d["atomic_nums"][s * n:(s + 1) * n]
+        ref = om.bond_graph(d["xyz"][s * n:(s + 1) * n], table[z - 1])
+        gen = om.bond_graph(d["xyz_recon"][s * n:(s + 1) * n], table[z - 1])
+        hvy = (z != 1)[:, None] & (z != 1)[None, :]
+        want = [int(ref.sum()) // 2, int(gen.sum()) // 2, int((ref != gen).sum()) // 2,
+                int((ref * hvy).sum()) // 2, int((gen * hvy).sum()) // 2, int(((ref != gen) & hvy).sum()) // 2]
+        assert cnt[s].tolist() == want
+
+
+def test_cli_evaluation_block_reports_the_reference_summary():
+    """test.py's Evaluation (the reference loop's evaluation block, test.py:566-668, on the device): one ensemble
+    member of a fabricated batch -> the summary keys the reference prints, values equal to the helper calls."""
+    import importlib.util
+    import os
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("codlad_cli_eval", os.path.join(root, "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    d = on_gpu(cases.metric_inputs("small"))
+    n_atoms = d["xyz"].shape[0] // 2                                   # two frames of n_atoms atoms
+    z = torch.full((2 * n_atoms,), 6.0, device=DEV)
+    batch = {"nxyz": torch.cat([z[:, None], d["xyz"]], 1), "num_atoms": torch.tensor([n_atoms, n_atoms]),
+             "bond_edge_list": d["edge_list"], "nbr_list": d["nbr_list"], "bb_NO_list": d["bb_NO_list"],
+             "interaction_list": d["interaction_list"], "pi_pi_list": d["pi_pi_list"], "ic": d["ic"], "mask": d["mask"],
+             "mask_xyz_list": torch.tensor([3, 77], device=DEV)}
+    ev = cli.Evaluation()
+    for member in range(2):
+        ev.add(batch, d["ic_recon"], (d["xyz_recon"] + 0.01 * member).reshape(2, n_atoms, 3), n_atoms)
+    args = types.SimpleNamespace(data_type="PED", num_ensemble=2, experiment="latent")
+    stats = ev.report("fabricated", args)
+    for k in ("test_all_recon", "test_xyz", "test_graph", "test_nbr", "test_inter", "test_pi_pi", "test_all_valid_ratio",
+              "test_all_ged", "diversity"):
+        assert k in stats and np.isfinite(stats[k]), k
+    xyz, xr = d["xyz"].clone(), d["xyz_recon"].clone()
+    xyz[batch["mask_xyz_list"]] *= 0
+    xr[batch["mask_xyz_list"]] *= 0
+    want0 = float(gm.xyz_result(xr, xyz))
+    assert ev.rows[0]["loss_xyz"] == want0
+    assert 0.0 <= stats["test_all_valid_ratio"] <= 1.0
+
+
+def test_superposed_rmsd_is_invariant_to_rigid_motion():
+    """Kabsch RMSD (stands in for mdtraj's md.rmsd in the diversity score; unpinned): zero for a rotated + shifted
+    copy, equal to the plain RMSD when the optimal superposition is the identity."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(200, 3, generator=g, dtype=torch.float64) * 5
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    if torch.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    b = a @ q.t() + torch.tensor([1.0, -2.0, 3.0], dtype=torch.float64)
+    assert gm.superposed_rmsd(a, b) < 1e-6
+    noise = torch.randn(200, 3, generator=g, dtype=torch.float64) * 0.01
+    r = gm.superposed_rmsd(a, a + noise)
+    assert r <= float(noise.pow(2).sum(-1).mean().sqrt()) + 1e-12
+    gen = [a[None] + 0.1 * torch.randn(1, 200, 3, generator=g, dtype=torch.float64) for _ in range(4)]
+    div = gm.compute_div(gen, a[None] + 0.3)
+    assert 0.0 < div < 1.0

@@ -215,3 +215,18 @@ def test_g10_envelope_weight_sets(name):
         z, eps = cases.loop_noise(10, B, L, seed)
         xs = sampler.p_sample_loop(wsd, 10, z, eps, cg_xyz, cg_z, mask)
         assert rel_err(xs, gold["sample"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(cases.VALIDITY_CASES))
+def test_g11_bond_graph_validity(name):
+    """oracle/metrics.valid_ratio_and_cut_off_result against the reference's (ase.Atoms stood in for by a plain
+    container when the golden was made: it carries no arithmetic on this path)."""
+    from codlad_amd.metrics import COV_CUTOFF
+    from oracle import metrics as om
+    gold = g(f"g11_validity_{name}")
+    d = cases.validity_inputs(name)
+    hv, av, hg, ag = om.valid_ratio_and_cut_off_result(d["xyz"], d["xyz_recon"], d["num_atoms"].tolist(),
+                                                       d["atomic_nums"], COV_CUTOFF)
+    assert hv == gold["heavy_valid"].tolist() and av == gold["all_valid"].tolist()
+    assert np.array_equal(np.array(hg, dtype=np.float64), gold["heavy_ged"])
+    assert np.array_equal(np.array(ag, dtype=np.float64), gold["all_ged"])

@@ -77,6 +77,45 @@ def save(name, **arrays):
 
 
 # ----------------------------------------------------------------------------
+def g11_validity(ref):
+    """Bond-graph validity of reconstructions: the reference's valid_ratio_and_cut_off_result (test.py:168-188 ->
+    utils/protein_module.py:251-364).  ase is not installed; the reference uses ase.Atoms only as a container of
+    (numbers, positions) on this path, so a container with those two accessors stands in for it (the arithmetic -
+    distance matrix, covalent cut-offs, graph comparison - is all the reference's own)."""
+    import importlib.util
+
+    class Atoms:
+        def __init__(self, numbers=None, positions=None):
+            self._z, self._x = np.asarray(numbers), np.asarray(positions, dtype=np.float64)
+
+        def get_positions(self):
+            return self._x
+
+        def get_atomic_numbers(self):
+            return self._z
+
+        def __len__(self):
+            return len(self._z)
+
+    sys.modules["ase"].Atoms = Atoms
+    import utils.protein_module as pm
+    pm.Atoms = Atoms
+    spec = importlib.util.spec_from_file_location("reference_test_script_v", os.path.join(ref["root"], "test.py"))
+    rt = importlib.util.module_from_spec(spec)
+    quiet(spec.loader.exec_module, rt)
+    rt.Atoms = Atoms
+    print("g11 bond-graph validity")
+    from codlad_amd.metrics import COV_CUTOFF
+    assert tuple(pm.COVCUTOFFTABLE[k] for k in range(1, 108)) == COV_CUTOFF      # the table kept as data is the reference's
+    for name in cases.VALIDITY_CASES:
+        d = cases.validity_inputs(name)
+        hv, av, hg, ag = rt.valid_ratio_and_cut_off_result(d["xyz"], d["xyz_recon"], d["num_atoms"], d["atomic_nums"])
+        save(f"g11_validity_{name}", heavy_valid=np.array(hv), all_valid=np.array(av),
+             heavy_ged=np.array(hg, dtype=np.float64), all_ged=np.array(ag, dtype=np.float64))
+        print("   ", name, hv, av, [round(x[0], 4) for x in hg], [round(x[0], 4) for x in ag])
+
+
+# ----------------------------------------------------------------------------
 def g10_envelope(ref):
     """Weight sets that probe the split-fp16 contraction modes' envelope (tests/cases.py ENVELOPE_CASES): one
     forward of the reference per set, plus a 10-step loop for the reference constructor's own initialisation."""
@@ -434,6 +473,7 @@ def main():
     if want("g8"): g8_metrics(ref)
     if want("g9"): g9_self_condition(ref)
     if want("g10"): g10_envelope(ref)
+    if want("g11"): g11_validity(ref)
 
 
 if __name__ == "__main__":
