@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 6   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 7   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -48,7 +48,7 @@ class DenoiserWeights(C.Structure):
                [(n, P) for n in ("x_in_w", "x_in_b", "pos_w", "pos_b", "edge_wT", "norm_w", "norm_b",
                                  "We_wT", "We_b", "out_w", "out_b")] + \
                [("enc", EncLayer * 3), ("dec", DecLayer * 3), ("precision", C.c_int),
-                ("enc_h", EncLayerH * 3), ("dec_h", DecLayerH * 3), ("self_condition", C.c_int)]
+                ("enc_h", EncLayerH * 3), ("dec_h", DecLayerH * 3), ("self_condition", C.c_int), ("out_dim", C.c_int)]
 
 
 class Workspace(C.Structure):
@@ -84,6 +84,8 @@ _SIGS = {
     "codlad_pack_block_host": (None, [P, C.c_int, C.c_float, P]),
     "codlad_features_prepass": (C.c_int, [C.POINTER(DenoiserWeights), P, P, C.c_int, C.c_int, P, P, P]),
     "codlad_step_mods": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P]),
+    "codlad_step_mods_f": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P]),
+    "codlad_ode_combine": (C.c_int, [P, P, P, C.c_int, C.c_float, C.c_size_t, P, P]),
     "codlad_layer0_edge_terms": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P]),
     "codlad_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P, C.c_int, P, P, P, P,
                                           C.POINTER(Workspace), P]),

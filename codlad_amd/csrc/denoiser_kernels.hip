@@ -560,6 +560,7 @@ struct FinalArgs {
     const float *coef;  // device [8]
     float *x_start;     // [n][3] or null: pred_xstart of this step (self-conditioning input of the next)
     int *status;        // sticky status word or null (CODLAD_STATUS_NONFINITE)
+    int n_out;          // 6 (eps | variance logits, diffusion) or 3 (velocity, flow matching: logits mode only)
 };
 
 // 32 lanes per node (one 16-byte word of the row each: coalesced 512-byte row reads, the reductions are
@@ -586,8 +587,11 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
     float o[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const float4 w = reinterpret_cast<const float4 *>(a.out_w + k * HD)[l];
-        o[k] = half_wave_allsum(fmaf(m3, w.w, fmaf(m2, w.z, fmaf(m1, w.y, m0 * w.x)))) + a.out_b[k];
+        o[k] = 0.f;
+        if (k < a.n_out) {
+            const float4 w = reinterpret_cast<const float4 *>(a.out_w + k * HD)[l];
+            o[k] = half_wave_allsum(fmaf(m3, w.w, fmaf(m2, w.z, fmaf(m1, w.y, m0 * w.x)))) + a.out_b[k];
+        }
     }
     if (!live) return;
     if (a.status && l == 0) {
@@ -604,11 +608,11 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
         if (bad) atomicOr(a.status, CODLAD_STATUS_NONFINITE);
     }
     if (a.logits) {
-        if (l < 6) {
+        if (l < a.n_out) {
             float mine = o[0];
 #pragma unroll
             for (int k = 1; k < 6; ++k) mine = l == k ? o[k] : mine;
-            a.logits[(size_t)n * 6 + l] = mine;
+            a.logits[(size_t)n * a.n_out + l] = mine;
         }
         return;
     }
@@ -636,13 +640,13 @@ __global__ void ddpm_kernel(const float *x, const float *out, const float *noise
 // ---------------------------------------------------------------------------------------------
 // Timestep embedding + all adaLN heads, one workgroup per timestep (row 3).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mods_kernel(codlad_denoiser_weights w, const int64_t *tv,
+__global__ __launch_bounds__(256) void mods_kernel(codlad_denoiser_weights w, const int64_t *tv, const float *tf,
                                                   float *mods) {
     __shared__ float emb[256];
     __shared__ float hid[HD];
     __shared__ float sc[HD];
     const int tid = threadIdx.x;
-    const float t = (float)tv[blockIdx.x];
+    const float t = tv ? (float)tv[blockIdx.x] : tf[blockIdx.x];   // latent_model.py:66: t[:, None].float() * freqs
     {
         const int k = tid & 127;
         const float arg = t * w.freqs[k];
@@ -957,9 +961,18 @@ extern "C" int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t 
                                 float *mods, void *stream) {
     CODLAD_REQUIRE(w && t_values && mods, "null pointer");
     CODLAD_REQUIRE(n_t > 0, "n_t must be positive");
-    hipLaunchKernelGGL(mods_kernel, dim3(n_t), dim3(256), 0, (hipStream_t)stream, *w, t_values, mods);
+    hipLaunchKernelGGL(mods_kernel, dim3(n_t), dim3(256), 0, (hipStream_t)stream, *w, t_values, (const float *)nullptr, mods);
     return codlad_check_launch("codlad_step_mods");
 }
+
+extern "C" int codlad_step_mods_f(const codlad_denoiser_weights *w, const float *t_values, int n_t, float *mods,
+                                  void *stream) {
+    CODLAD_REQUIRE(w && t_values && mods, "null pointer");
+    CODLAD_REQUIRE(n_t > 0, "n_t must be positive");
+    hipLaunchKernelGGL(mods_kernel, dim3(n_t), dim3(256), 0, (hipStream_t)stream, *w, (const int64_t *)nullptr, t_values, mods);
+    return codlad_check_launch("codlad_step_mods_f");
+}
+
 
 extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *node_info,
                                        int n_nodes, const int32_t *E_idx, const float *h_E0,
@@ -971,10 +984,11 @@ extern "C" int codlad_denoiser_forward(const codlad_denoiser_weights *w, const i
     CODLAD_REQUIRE(n_nodes > 0, "n_nodes must be positive");
     hipStream_t st = (hipStream_t)stream;
     CODLAD_REQUIRE(!x_self_cond || w->self_condition, "x_self_cond given to a model without self-conditioning");
+    CODLAD_REQUIRE(w->out_dim == 6 || w->out_dim == 3, "out_dim must be 6 (diffusion) or 3 (flow matching)");
     enqueue_forward(w, node_info, n_nodes, E_idx, h_E0, E1, (size_t)n_snodes, x, x_self_cond, mods_t, ws, st);
     FinalArgs fa = {};
     fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
-    fa.n_nodes = n_nodes; fa.logits = out; fa.status = ws->status;
+    fa.n_nodes = n_nodes; fa.logits = out; fa.status = ws->status; fa.n_out = w->out_dim;
     hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 7) / 8), dim3(256), 0, st, fa);
     return codlad_check_launch("codlad_denoiser_forward");
 }
@@ -1000,6 +1014,7 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
     CODLAD_REQUIRE(n_nodes > 0 && T > 0, "n_nodes and T must be positive");
     CODLAD_REQUIRE(!w->self_condition || x_start, "a self-conditioned model needs the x_start buffer");
+    CODLAD_REQUIRE(w->out_dim == 6, "the DDPM loop needs a diffusion model (eps | variance logits, out_dim 6)");
     hipStream_t st = (hipStream_t)stream;
     // self-conditioning (gaussian_diffusion.py:530-547): step k reads the pred_xstart step k-1 wrote;
     // the first step gets none, which the model treats as zeros (latent_model.py:211)
@@ -1012,7 +1027,7 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
         FinalArgs fa = {};
         fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
         fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
-        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start; fa.status = ws->status;
+        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start; fa.status = ws->status; fa.n_out = 6;
         hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 7) / 8), dim3(256), 0, st, fa);
     }
     return codlad_check_launch("codlad_sample_loop");

@@ -159,13 +159,20 @@ class Denoiser:
 
     def step_mods(self, t_values, refresh=False):
         """[len(t_values), 6016] adaLN modulation vectors; cached per timestep list (refresh: run the
-        kernel again even if cached)."""
-        key = tuple(int(t) for t in t_values)
+        kernel again even if cached).  Integer timesteps (diffusion) or fractional ones (flow matching: any
+        non-integer value switches the whole list to the float entry point)."""
+        fractional = any(float(t) != int(t) for t in t_values)
+        key = tuple(float(t) for t in t_values) if fractional else tuple(int(t) for t in t_values)
         if refresh or key not in self._mods_cache:
-            tv = torch.tensor(key, dtype=torch.int64, device=self.device)
             mods = torch.empty(len(key), MODS, dtype=torch.float32, device=self.device)
-            rc = self.lib.codlad_step_mods(C.byref(self.weights.struct), _lib.ptr(tv), len(key),
-                                           _lib.ptr(mods), _lib.stream_ptr(self.device))
+            if fractional:
+                tv = torch.tensor(key, dtype=torch.float32, device=self.device)
+                rc = self.lib.codlad_step_mods_f(C.byref(self.weights.struct), _lib.ptr(tv), len(key),
+                                                 _lib.ptr(mods), _lib.stream_ptr(self.device))
+            else:
+                tv = torch.tensor(key, dtype=torch.int64, device=self.device)
+                rc = self.lib.codlad_step_mods(C.byref(self.weights.struct), _lib.ptr(tv), len(key),
+                                               _lib.ptr(mods), _lib.stream_ptr(self.device))
             _lib.check(rc, "codlad_step_mods")
             if len(self._mods_cache) > 64:
                 self._mods_cache.clear()
@@ -197,7 +204,7 @@ class Denoiser:
             x_self_cond = x_self_cond.contiguous().float()
             assert x_self_cond.shape == x.shape
         mods = self.step_mods([t_value])
-        out = torch.empty(job.n_nodes, 6, dtype=torch.float32, device=self.device)
+        out = torch.empty(job.n_nodes, self.weights.out_dim, dtype=torch.float32, device=self.device)
         st = job.structures
         self._fresh_features(st)
         rc = self.lib.codlad_denoiser_forward(C.byref(self.weights.struct), _lib.ptr(job.node_info),
@@ -218,6 +225,9 @@ class Denoiser:
         _require_cuda(noise, "noise")
         T = tables.num_timesteps
         assert noise.shape == (T, job.n_nodes, 3) and x_T.shape == (job.n_nodes, 3)
+        if self.weights.out_dim != 6:
+            raise ValueError("the DDPM loop needs a diffusion model; a flow-matching model is sampled with "
+                             "codlad_amd.diffusion_and_flow.ode.odeint")
         x = x_T.detach().clone().contiguous().float()
         noise = noise.contiguous().float()
         mods = self.step_mods(tables.timestep_map)

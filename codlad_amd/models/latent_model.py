@@ -95,8 +95,8 @@ class ProteinMPNN_diffusion_new(nn.Module):
             unsupported.append("k_neighbors != 64 / vocab != 30 / full-backbone features")
         if augment_eps != 0.0 or decoder_mask or not use_seq_in_encoder or use_input_decoding_order:
             unsupported.append("anything but the `mpnn_diffusion` configuration")
-        if not final_adln or diffusion != "diffusion" or input_size != 3:
-            unsupported.append("plain output head / non-DDPM heads / latent_size != 3")
+        if not final_adln or input_size != 3 or not isinstance(diffusion, str):
+            unsupported.append("plain output head / latent_size != 3 / no sampler name")
         if unsupported:
             raise NotImplementedError("the HIP path builds the reference's mpnn_diffusion model only; "
                                       "not supported: " + "; ".join(unsupported))
@@ -113,7 +113,10 @@ class ProteinMPNN_diffusion_new(nn.Module):
                                              for _ in range(num_encoder_layers)])
         self.decoder_layers = nn.ModuleList([_DecLayerParams(hidden_dim, hidden_dim * 3)
                                              for _ in range(num_decoder_layers)])
-        self.W_out = _FinalParams(hidden_dim, input_size * 2)
+        # latent_model.py:142-143: eps | variance logits for the DDPM model, the velocity alone for the flow-matching
+        # models (--model fm / icfm / otcfm / ..., reference test.py:196)
+        self.diffusion = diffusion
+        self.W_out = _FinalParams(hidden_dim, input_size * 2 if diffusion == "diffusion" else input_size)
         # same initialisation policy as the reference (latent_model.py:151-165)
         for p in self.parameters():
             if p.dim() > 1:
@@ -179,10 +182,10 @@ class ProteinMPNN_diffusion_new(nn.Module):
         n_rep = N // B
         job, lens = self.job_for(batch, n_rep)
         self._check_mask(mask, lens, n_rep)
-        tt = t.reshape(-1)
-        t0 = int(tt[0])
-        if tt.numel() > 1 and not bool((tt == t0).all()):
-            raise NotImplementedError("per-sample timesteps: the sampler uses one timestep per call")
+        tt = t.reshape(-1)                     # latent_model.py:191-194: a scalar t is expanded over the batch
+        t0 = float(tt[0]) if tt.is_floating_point() else int(tt[0])
+        if tt.numel() > 1 and not bool((tt == tt[0]).all()):
+            raise NotImplementedError("per-sample timesteps: the samplers use one timestep per call")
         if len(set(lens)) != 1:
             # the reference pads such a batch and its result then DIFFERS from each sample alone: K = min(64, L_max)
             # and the decoder layers sum over padded neighbours (protein_mpnn_utils.py:304-307, mask_attend=None)

@@ -69,7 +69,7 @@ def _linear(rng, sd, name, out_f, in_f, bias=True, gain=1.0, bias_std=0.1):
         sd[f"{name}.bias"] = _t(rng.standard_normal((out_f,)) * bias_std)
 
 
-def denoiser_state_dict(seed=1234, input_size=3, self_condition=False):
+def denoiser_state_dict(seed=1234, input_size=3, self_condition=False, flow=False):
     """Non-degenerate weights with the key layout of the reference's
     `ProteinMPNN_diffusion_new` (108 tensors; reference models/latent_model.py:119-148).
 
@@ -109,7 +109,8 @@ def denoiser_state_dict(seed=1234, input_size=3, self_condition=False):
         _linear(rng, sd, f"{p}.dense.W_in", 4 * H, H, gain=1.5)
         _linear(rng, sd, f"{p}.dense.W_out", H, 4 * H, gain=1.5)
         _linear(rng, sd, f"{p}.adaLN_modulation.1", 6 * H, H, gain=1.0, bias_std=0.5)
-    _linear(rng, sd, "W_out.linear", 2 * input_size, H, gain=1.0)
+    # flow-matching models (--model fm / otcfm / ...) predict the velocity only (reference latent_model.py:142-143)
+    _linear(rng, sd, "W_out.linear", input_size if flow else 2 * input_size, H, gain=1.0)
     _linear(rng, sd, "W_out.adaLN_modulation.1", 2 * H, H, gain=1.0, bias_std=0.5)
     return sd
 

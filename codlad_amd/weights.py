@@ -145,7 +145,8 @@ def denoiser_tensors(sd):
     t["norm_w"], t["norm_b"] = g("features.norm_edges.weight"), g("features.norm_edges.bias")
     t["We_wT"], t["We_b"] = g("W_e.weight").t().contiguous(), g("W_e.bias")
     t["out_w"], t["out_b"] = g("W_out.linear.weight"), g("W_out.linear.bias")
-    assert t["out_w"].shape == (6, H)
+    # 6 rows: eps | variance logits (diffusion); 3 rows: velocity (flow matching, latent_model.py:142-143)
+    assert t["out_w"].shape in ((6, H), (3, H)), "W_out.linear must have 2 * 3 (diffusion) or 3 (flow) rows"
     for l in range(3):
         p = f"encoder_layers.{l}"
         W1, W11 = g(f"{p}.W1.weight"), g(f"{p}.W11.weight")
@@ -349,6 +350,7 @@ class DenoiserWeights:
         self.blob = Blob(tensors, device)
         self.precision = precision
         self.self_condition = tensors["x_in_w"].shape[1] == 6
+        self.out_dim = int(tensors["out_w"].shape[0])
         self.struct = self._fill()
 
     def _fill(self):
@@ -384,6 +386,7 @@ class DenoiserWeights:
                 dh.Win[c], dh.Wout[c] = p(f"h.dec{l}.Win{c}"), p(f"h.dec{l}.Wout{c}")
         w.precision = PRECISIONS[self.precision]
         w.self_condition = int(self.self_condition)
+        w.out_dim = self.out_dim
         return w
 
     def set_precision(self, precision):

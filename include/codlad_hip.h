@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 6
+#define CODLAD_ABI_VERSION 7
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -114,7 +114,7 @@ typedef struct {
     const float *edge_wT;              /* features.edge_embedding.weight TRANSPOSED [167][128] */
     const float *norm_w, *norm_b;      /* features.norm_edges                                   */
     const float *We_wT, *We_b;         /* W_e.weight TRANSPOSED [128][128], [128]              */
-    const float *out_w, *out_b;        /* W_out.linear [6][128], [6]                           */
+    const float *out_w, *out_b;        /* W_out.linear [out_dim][128], [out_dim]               */
     codlad_enc_layer enc[3];
     codlad_dec_layer dec[3];
     /* 0: contractions on v_mfma_f32_32x32x2_f32 (exact fp32 products);
@@ -133,6 +133,9 @@ typedef struct {
      * cat(x_self_cond, x) and the sampler feeds each step the previous step's pred_xstart
      * (gaussian_diffusion.py:530-547). */
     int self_condition;
+    /* rows of W_out.linear: 6 = (eps | variance logits) of a diffusion model, 3 = the velocity of a flow-matching
+     * model (latent_model.py:142-143: input_size is doubled for diffusion == "diffusion" only) */
+    int out_dim;
 } codlad_denoiser_weights;
 
 /* Row 4: CA_ProteinFeatures.forward + W_e
@@ -152,6 +155,16 @@ int codlad_features_prepass(const codlad_denoiser_weights *w, const float *cg_xy
  * t_values: DEVICE int64 [n_t] (already mapped through timestep_map).  mods [n_t][6016]. */
 int codlad_step_mods(const codlad_denoiser_weights *w, const int64_t *t_values, int n_t,
                      float *mods, void *stream);
+
+/* The same for FRACTIONAL timesteps (device float [n_t]): the flow-matching sampler evaluates the model at
+ * t in [0, 1] (reference test.py:214-250; latent_model.py:66 multiplies t.float() into the frequencies). */
+int codlad_step_mods_f(const codlad_denoiser_weights *w, const float *t_values, int n_t, float *mods, void *stream);
+
+/* Next row 8f-4 (flow matching / ODE sampling, reference test.py:214-250 -> torchdiffeq.odeint): the update of
+ * an explicit Runge-Kutta step, out[i] = y[i] + sum_j k[j][i] * (coef[j] * h), j < n_k <= 7, each operation
+ * rounded separately, summed left to right.  k_host: HOST array of n_k DEVICE pointers; coef_host: HOST floats. */
+int codlad_ode_combine(const float *y, const float *const *k_host, const float *coef_host, int n_k, float h,
+                       size_t n, float *out, void *stream);
 
 /* Workspace of one job, all caller-allocated. */
 typedef struct {
@@ -190,6 +203,7 @@ int codlad_layer0_edge_terms(const codlad_denoiser_weights *w, const int32_t *sn
                              int n_snodes, const float *h_E0, float *E1, void *stream);
 
 /* Rows 5-7: one denoiser forward (latent_model.py:175-268): x [n_nodes][3] -> out [n_nodes][6].
+ * (out [n_nodes][3] for a flow-matching model, out_dim 3).
  * mods_t = the 6016 modulation floats of this timestep.  E1 (may be NULL) from
  * codlad_layer0_edge_terms, n_snodes = its structure-node count.  x_self_cond [n_nodes][3]: only for
  * a self_condition model, NULL = zeros (latent_model.py:211). */

@@ -39,7 +39,8 @@ def build_model(args):
 def load_denoiser(args, device):
     model = build_model(args)
     if args.synthetic_weights:
-        model.load_state_dict(synth.denoiser_state_dict(1234, self_condition=args.self_condition), strict=True)
+        model.load_state_dict(synth.denoiser_state_dict(1234, self_condition=args.self_condition,
+                                                        flow=args.model != "diffusion"), strict=True)
     else:
         tag = {"best": "best", "last": "last"}.get(args.model_step, f"step_{args.model_step}")
         ckpt = torch.load(f"./results/{args.exp}/protein_weights_{tag}.pt", map_location="cpu")
@@ -142,6 +143,16 @@ class Evaluation:
         return stats
 
 
+def run_sampling(model, args, x, mask=None, batch=None):
+    """Flow-matching sampling, reference test.py:214-250: integrate dx/dt = model(x, t) from t = 0 (noise) to 1 over
+    t_span = linspace(0, 1, --steps) with --method / --atol / --rtol; torchdiffeq.odeint is replaced by
+    codlad_amd.diffusion_and_flow.ode.odeint (euler / midpoint / rk4 / dopri5)."""
+    from codlad_amd.diffusion_and_flow.ode import odeint
+    t_span = torch.linspace(0, 1, args.steps).to(x.device)
+    fwd = lambda t, x_in: model.forward(x_in, t, None, mask=mask, batch=batch)  # noqa: E731
+    return odeint(fwd, x, t_span, rtol=args.rtol, atol=args.atol, method=args.method)[-1]
+
+
 def main(args):
     if not torch.cuda.is_available():
         raise SystemExit("test.py (codlad_amd) needs an MI355X: there is no CPU path")
@@ -169,7 +180,7 @@ def main(args):
     vae = load_vae(args, device)
     if args.experiment == "latent":
         model = load_denoiser(args, device)
-        diffusion = create_diffusion(str(args.num_sampling_steps), noise_schedule=args.noise_schedule,
+        diffusion = None if args.model != "diffusion" else create_diffusion(str(args.num_sampling_steps), noise_schedule=args.noise_schedule,
                                      predict_xstart=args.predict_xstart,
                                      rescale_learned_sigmas=args.rescale_learned_sigmas,
                                      # reference test.py:297-303
@@ -195,8 +206,11 @@ def main(args):
         rep = {k: v for k, v in batch.items()}
         if args.experiment == "latent":
             z = torch.randn(B * E, L, args.latent_size, device=device)
-            samples = diffusion.p_sample_loop(model.forward, z.shape, z, clip_denoised=False,
-                                              model_kwargs=dict(y=None, mask=mask, batch=rep), device=device)
+            if args.model == "diffusion":
+                samples = diffusion.p_sample_loop(model.forward, z.shape, z, clip_denoised=False,
+                                                  model_kwargs=dict(y=None, mask=mask, batch=rep), device=device)
+            else:                                               # --model fm / icfm / otcfm ...: ODE sampling
+                samples = run_sampling(model, args, z, mask=mask, batch=rep)
             samples = get_norm_feature(samples, args.vae_type, norm_channel=args.norm, norm_single=args.norm_single,
                                        norm_in=False, dataname=args.data_type)
         else:
@@ -233,8 +247,7 @@ def main(args):
 
 if __name__ == "__main__":
     p = argparse.ArgumentParser("parameters")
-    # names and defaults as in the reference (test.py:894-961); flags of the ODE / flow samplers
-    # (--method, --atol, --rtol, --steps, --compute_nfe ...) are accepted and ignored
+    # names and defaults as in the reference (test.py:894-961)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--exp", default="experiment_cifar_default")
     p.add_argument("--cond", action="store_true", default=False)
@@ -262,12 +275,14 @@ if __name__ == "__main__":
     for ignored, kw in (("--compute_nfe", dict(action="store_true")), ("--iteration", dict(type=int, default=1000)),
                         ("--n_sample", dict(type=int, default=50000)), ("--dataset", dict(default="cifar10")),
                         ("--num_steps", dict(type=int, default=40)), ("--batch_size", dict(type=int, default=200)),
-                        ("--atol", dict(type=float, default=1e-5)), ("--rtol", dict(type=float, default=1e-5)),
-                        ("--method", dict(type=str, default="dopri5")), ("--steps", dict(type=int, default=2)),
                         ("--feature_path", dict(type=str, default="./datasets/features_N6")),
                         ("--gcn_layernorm", dict(action="store_true", default=True)),
                         ("--forward_inf", dict(action="store_true", default=False))):
         p.add_argument(ignored, **kw)
+    p.add_argument("--atol", type=float, default=1e-5)
+    p.add_argument("--rtol", type=float, default=1e-5)
+    p.add_argument("--method", type=str, default="dopri5")
+    p.add_argument("--steps", type=int, default=2)
     # additions
     p.add_argument("--data_files", nargs="*", default=[], help="with --data_process: pickles of (list of frame dicts, info)")
     p.add_argument("--synthetic", action="store_true", help="synthetic PED/PDB/Atlas-shaped proteins")

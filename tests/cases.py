@@ -196,6 +196,17 @@ def metric_inputs(name):
                 interaction_list=t(inter), pi_pi_list=t(pipi), ic=t(ic), ic_recon=t(ic_recon), mask=t(mask))
 
 
+# flow-matching models: name -> (n_cg, n_frames, seed, fractional times of the forward goldens,
+# fixed-grid steps of the sampled trajectories)
+# (one frame per batch is not a case: the reference's forward fails on a 0-d t when the batch holds a single structure,
+# latent_model.py:193-194 leaves it 0-d and :66 indexes it)
+# Geometry seeds are those of DENOISER_CASES: a perturbed frame whose consecutive CA steps leave the 3.6-4.0 A window gets
+# zeroed local frames (protein_mpnn_utils.py:400), and the quaternion between two zeroed frames is 0/0 up to rounding -
+# the reference's own fp32 and fp64 evaluations then differ by 1.0 in that feature (seen with seed 72, frame 1,
+# residues 24/25), so such an edge cannot be a parity case.
+FLOW_CASES = {"L46_B2": (46, 2, 12, (0.0, 0.37, 1.0), 8), "L87_B2": (87, 2, 13, (0.5,), 5)}
+
+
 VALIDITY_CASES = {"tight": 0.02, "loose": 0.12, "broken": 0.45}     # name -> coordinate noise of the reconstruction (A)
 
 

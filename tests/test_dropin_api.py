@@ -48,8 +48,10 @@ def test_unsupported_configurations_fail_loudly():
     from codlad_amd.models.latent_model import ProteinMPNN_diffusion_new
     with pytest.raises(NotImplementedError):
         ProteinMPNN_diffusion_new(input_size=36, diffusion="diffusion")       # default ctor = not mpnn_diffusion
+    fm = MPNN_models["mpnn_diffusion"](input_size=3, diffusion="fm")            # flow matching: velocity head only
+    assert tuple(fm.W_out.linear.weight.shape) == (3, 128)                      # latent_model.py:142-143
     with pytest.raises(NotImplementedError):
-        MPNN_models["mpnn_diffusion"](input_size=3, diffusion="flow")
+        MPNN_models["mpnn_diffusion"](input_size=3, diffusion=False)            # no sampler family named
     sc = MPNN_models["mpnn_diffusion"](input_size=3, diffusion="diffusion", self_condition=True)
     assert sc.self_condition and tuple(sc.x_in.weight.shape) == (128, 6)        # latent_model.py:112-116
     with pytest.raises(NotImplementedError):

@@ -230,3 +230,25 @@ def test_g11_bond_graph_validity(name):
     assert hv == gold["heavy_valid"].tolist() and av == gold["all_valid"].tolist()
     assert np.array_equal(np.array(hg, dtype=np.float64), gold["heavy_ged"])
     assert np.array_equal(np.array(ag, dtype=np.float64), gold["all_ged"])
+
+
+@pytest.mark.parametrize("name", list(cases.FLOW_CASES))
+def test_g12_flow_matching_model_and_fixed_grid_solvers(name):
+    """Flow-matching model (velocity head, fractional t) against the reference model's outputs, and the oracle's
+    fixed-grid Euler / RK4 (3/8) loops over it against the trajectories gen_golden integrated over the reference
+    model (the solver layer itself is unpinned: torchdiffeq is absent)."""
+    from oracle import flow as oflow
+    L, B, seed, times, n_steps = cases.FLOW_CASES[name]
+    gold = g(f"g12_flow_{name}")
+    fsd = synth.denoiser_state_dict(cases.WEIGHT_SEED, flow=True)
+    assert fsd["W_out.linear.weight"].shape == (3, 128)
+    prot, batch, x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    cg_z, cg_xyz, m = denoiser.batch_to_dense(batch)
+    f = oflow.velocity_fn(fsd, cg_xyz, cg_z, mask)
+    for k, t in enumerate(times):
+        v = f(t, x)
+        assert v.shape == (B, L, 3) and rel_err(v, gold[f"v_t{k}"]) < 2e-6
+    ts = torch.linspace(0, 1, n_steps + 1).tolist()
+    for method in ("euler", "rk4"):
+        y = oflow.odeint_fixed(f, x, ts, method)[-1]
+        assert rel_err(y, gold[method]) < 1e-5, method

@@ -77,6 +77,39 @@ def save(name, **arrays):
 
 
 # ----------------------------------------------------------------------------
+def g12_flow(ref):
+    """Next row 8f-4: a flow-matching model (--model fm: W_out has input_size rows, latent_model.py:142-143) evaluated
+    at fractional times the way run_sampling's lambda does (test.py:231: model.forward(x_in, t, y1, mask, batch) with
+    a scalar t) - PINNED by the reference model; and fixed-grid Euler / RK4 (3/8 rule) trajectories over that model
+    with the solver loops written here (torchdiffeq is not installed: the solver layer is unpinned)."""
+    print("g12 flow matching")
+    model = ref["MPNN_models"]["mpnn_diffusion"](input_size=3, unconditional=True, diffusion="fm", self_condition=False)
+    model.load_state_dict(synth.denoiser_state_dict(cases.WEIGHT_SEED, flow=True), strict=True)
+    model.eval()
+    for name, (L, B, seed, times, n_steps) in cases.FLOW_CASES.items():
+        prot, batch, x, _t, mask = cases.denoiser_inputs(L, B, seed)
+        f = lambda t, y: model.forward(y, torch.tensor(t, dtype=torch.float32), None, mask=mask, batch=batch)  # noqa: E731
+        arrays = {f"v_t{k}": f(t, x) for k, t in enumerate(times)}
+        ts = torch.linspace(0, 1, n_steps + 1).tolist()
+        h32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+        y = x
+        for t0, t1 in zip(ts, ts[1:]):                       # Euler
+            y = y + f(t0, y) * (h32(1.0) * h32(t1 - t0))
+        arrays["euler"] = y
+        y = x
+        for t0, t1 in zip(ts, ts[1:]):                       # RK4, 3/8 rule
+            dt = t1 - t0
+            k1 = f(t0, y)
+            k2 = f(t0 + dt / 3, y + k1 * (h32(1 / 3) * h32(dt)))
+            k3 = f(t0 + dt * 2 / 3, y + (k2 * (h32(1.0) * h32(dt)) + k1 * (h32(-1 / 3) * h32(dt))))
+            k4 = f(t1, y + ((k1 * (h32(1.0) * h32(dt)) + k2 * (h32(-1.0) * h32(dt))) + k3 * (h32(1.0) * h32(dt))))
+            y = y + (((k1 * (h32(0.125) * h32(dt)) + k2 * (h32(0.375) * h32(dt))) + k3 * (h32(0.375) * h32(dt)))
+                     + k4 * (h32(0.125) * h32(dt)))
+        arrays["rk4"] = y
+        save(f"g12_flow_{name}", **arrays)
+
+
+# ----------------------------------------------------------------------------
 def g11_validity(ref):
     """Bond-graph validity of reconstructions: the reference's valid_ratio_and_cut_off_result (test.py:168-188 ->
     utils/protein_module.py:251-364).  ase is not installed; the reference uses ase.Atoms only as a container of
@@ -474,6 +507,7 @@ def main():
     if want("g9"): g9_self_condition(ref)
     if want("g10"): g10_envelope(ref)
     if want("g11"): g11_validity(ref)
+    if want("g12"): g12_flow(ref)
 
 
 if __name__ == "__main__":
