@@ -9,7 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
-SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_tile_kernels.hip", "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
+SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_tile_kernels.hip",
+           "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
            "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
 # and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
@@ -21,6 +22,8 @@ EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip":
                # each (3 instructions for min(|x|, c)); nothing on this path produces or tests NaN
                "denoiser_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_tile_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               "edge_msg_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               "edge_upd_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "node_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_args.h"), os.path.join(CSRC, "node_args.h"),
            os.path.join(HERE, "..", "include", "codlad_hip.h")]

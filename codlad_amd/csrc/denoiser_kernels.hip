@@ -73,235 +73,6 @@ __global__ __launch_bounds__(256, 2) void edge_kernel(EdgeArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Split-fp16 edge kernels (precision 1 = f16x4, 2 = f16x3).  Persistent 512-thread workgroups, one per CU: the two (three)
-// 64 KB weight blocks of the MLP live in LDS for the whole launch - 128 KB for the message kernel,
-// 152 KB for the edge update (W12, W13 and the first three k-steps of W11e; its last five k-steps
-// stream from L2, see below) - and every wave walks its nodes with a stride (wave_node_span).  The
-// contraction runs on the f16 matrix pipe, split / bias / GELU / reduction on the fp32 lanes.
-// ---------------------------------------------------------------------------------------------
-// Edge update, split-fp16 contractions:
-//   h_E[n,j] <- mod3(LN(h_E[n,j] + W13 GELU(W12 GELU(P_i + Q_j + W11e h_E[n,j]) + b12) + b13))
-// HOISTED: encoder layer 0 with a.E1 given - layer 1's edge contraction comes precomputed.
-template <int NWAVES, bool HOISTED, int TERMS>
-__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs a) {
-    extern __shared__ __align__(16) u32x4 wl[];
-    constexpr int NT = NWAVES * 64;
-    constexpr int W1_U4 = UPD_W1_KS * 512;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32x4 *consts = wl + 2 * LDS_BLOCK_U4 + W1_U4;
-    {
-        const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
-        const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
-        const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.W3h);
-        for (int i = tid; i < LDS_BLOCK_U4; i += NT) {
-            wl[i] = g2[i];
-            wl[LDS_BLOCK_U4 + i] = g3[i];
-        }
-        if (!HOISTED)
-            for (int i = tid; i < W1_U4; i += NT) wl[2 * LDS_BLOCK_U4 + i] = g1[i];
-        if (tid < 32) consts[tid] = reinterpret_cast<const u32x4 *>(a.b2)[tid];
-        if (tid >= 64 && tid < 96) consts[32 + (tid & 31)] = reinterpret_cast<const u32x4 *>(a.b3)[tid & 31];
-        if (tid >= 128 && tid < 160) {
-            // modulate folded to one multiply-add: A = gate (1 + scale), B = gate shift
-            const float4 *m = reinterpret_cast<const float4 *>(a.mods3);
-            const int i = tid & 31;
-            const float4 s = m[i], c = m[32 + i], g = m[64 + i];
-            float4 *cf = reinterpret_cast<float4 *>(consts);
-            cf[64 + i] = make_float4(g.x * (1.0f + c.x), g.y * (1.0f + c.y), g.z * (1.0f + c.z), g.w * (1.0f + c.w));
-            cf[96 + i] = make_float4(g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w);
-        }
-    }
-    __syncthreads();
-    const u32x4 *w2 = wl, *w3 = wl + LDS_BLOCK_U4, *w1 = wl + 2 * LDS_BLOCK_U4;
-    const float *c_base = reinterpret_cast<const float *>(consts);
-    float *Pslot = reinterpret_cast<float *>(consts + EDGE_CONST_U4 + wave * 32);
-    const int h = lane >> 5, c = lane & 31;
-    const NodeSpan span = wave_node_span(a.n_nodes, NWAVES, wave);
-    for (int n = span.first; n < span.end; n += span.stride) {
-        const int4 info = a.node_info[n];
-        const int src = info.x, base = info.y, K = info.z;
-        const float *rows = a.hE_in + (size_t)(a.in_by_src ? src : n) * EDGE_BLOCK;
-        float *out_rows = a.hE_out + (size_t)n * EDGE_BLOCK;
-        const bool validA = c < K, validB = 32 + c < K;
-        const int colA = validA ? c : 0, colB = validB ? 32 + c : 0;
-        const int jA = a.E_idx[(size_t)src * 64 + colA], jB = a.E_idx[(size_t)src * 64 + colB];
-        // this node's P row: one coalesced 512-byte read, staged in the wave's own LDS slot
-        // (same wave writes and reads: program order + lgkmcnt, no barrier)
-        reinterpret_cast<float2 *>(Pslot)[lane] = reinterpret_cast<const float2 *>(a.P + (size_t)n * HD)[lane];
-
-        for (int half = 0; half < 2; ++half) {
-            if (32 * half >= K) break;
-            const bool valid = half ? validB : validA;
-            const int colc = half ? colB : colA, col = 32 * half + c;
-            const int j = half ? jB : jA;
-            Tile x, acc, t2;
-            StreamedGemm<TERMS, UPD_W1_KS, 8 - UPD_W1_KS, false, 8> tail1;
-            if (!HOISTED) tail1.start(a.W1h, lane);
-            // the constants never change, so the compiler would read them once, before the node
-            // loop, into ~300 registers and spill those; an opaque zero offset keeps the reads here
-            int lds_off = 0;
-            asm volatile("" : "+v"(lds_off));
-            const float *c_b2 = c_base + lds_off, *c_b3 = c_b2 + HD;
-            const float *c_modA = c_b2 + 2 * HD, *c_modB = c_b2 + 3 * HD;
-            tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);
-            tile_add_row(acc, Pslot, h);
-            tile_load_edge(x, rows, colc, h);                          // layer-1 operand and residual
-            if (HOISTED) {
-                tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
-            } else {
-                gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps
-                tail1.run(acc, x, lane, a.gelu_a);                                    // layer 1, streamed k-steps
-            }
-            tile_load_row(t2, c_b2, h);
-            gemm128_h_lds<TERMS, true>(t2, acc, w2, lane, a.gelu_a);   // layer 2 on GELU(layer 1)
-            // layer 3 accumulates onto (h_E + b13) * 2^E: the input tile stays in registers for the
-            // residual instead of being fetched from HBM a second time (c_b3 holds b13 * 2^E)
-            tile_scale_add_row(x, a.res_scale, c_b3, h);
-            gemm128_h_lds<TERMS, true>(x, t2, w3, lane, a.gelu_b);     // layer 3 on GELU(layer 2)
-            tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);
-            if (valid) tile_store_edge(x, out_rows, col, h);
-        }
-    }
-}
-
-// Message kernel, split-fp16 contractions: S[n] = sum_j GELU(W2 GELU(P_i + Q_j + W1e h_E[i,j]) + b2) over the K
-// neighbours.  Same LDS residency scheme as upd_kernel_h; on top of that
-//   * the LAST contraction is issued with swapped MFMA operands, so its output block arrives
-//     transposed (lane = feature, registers = the tile's 32 edges): the sum over neighbours is
-//     then 15 register adds per block instead of a 5-step cross-lane reduction per register;
-//   * with the 64-register running sum gone, the next tile's edge rows are fetched while layer 2
-//     runs and its Q rows while the epilogue runs (a wave walks its (node, half) tiles in order).
-template <int NWAVES, bool HOISTED, int TERMS>
-__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs a) {
-    extern __shared__ __align__(16) u32x4 wl[];
-    constexpr int NT = NWAVES * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32x4 *consts = wl + 2 * LDS_BLOCK_U4;
-    {
-        const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.W1h);
-        const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.W2h);
-        for (int i = tid; i < LDS_BLOCK_U4; i += NT) {
-            if (!HOISTED) wl[i] = g1[i];
-            wl[LDS_BLOCK_U4 + i] = g2[i];
-        }
-        if (tid < 32) consts[tid] = reinterpret_cast<const u32x4 *>(a.b2)[tid];
-    }
-    __syncthreads();
-    const u32x4 *w1 = wl, *w2 = wl + LDS_BLOCK_U4;
-    const float *c_b2 = reinterpret_cast<const float *>(consts);
-    float2 *Pslot = reinterpret_cast<float2 *>(consts + EDGE_CONST_U4 + wave * 32);
-    const int h = lane >> 5, c = lane & 31;
-    const NodeSpan span = wave_node_span(a.n_nodes, NWAVES, wave);
-    const int stride = span.stride, n_end = span.end;
-    int n = span.first;                              // wave-uniform
-    if (n >= n_end) return;
-
-    const float *xsrc = HOISTED ? a.E1 : a.hE_in;    // layer-1 edge operand: hoisted term or h_E
-    auto block_of = [&](int node, int s) {
-        return xsrc + (size_t)((HOISTED || a.in_by_src) ? s : node) * EDGE_BLOCK;
-    };
-    const float2 *Prows = reinterpret_cast<const float2 *>(a.P);
-
-    int4 info = a.node_info[n];
-    int src = __builtin_amdgcn_readfirstlane(info.x), base = __builtin_amdgcn_readfirstlane(info.y);
-    int K = __builtin_amdgcn_readfirstlane(info.z);
-    int jA = a.E_idx[(size_t)src * 64 + (c < K ? c : 0)];
-    int jB = a.E_idx[(size_t)src * 64 + (32 + c < K ? 32 + c : 0)];
-    Pslot[lane] = Prows[(size_t)n * 64 + lane];
-    int half = 0;
-    Tile x, acc, t2;
-    tile_load_edge(x, block_of(n, src), c < K ? c : 0, h);
-    tile_load_row(acc, a.Q + (size_t)(base + jA) * HD, h);
-    float sum[4] = {0.f, 0.f, 0.f, 0.f};
-    float bias[4];
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo) bias[bo] = c_b2[32 * bo + c];
-
-    // the node after this one (kept equal to the current node when there is none, so that the
-    // prefetch below always has a valid address and needs no branch)
-    int4 ninfo = info;
-    int nsrc = src, nbase = base, nK = K, njA = jA, njB = jB;
-    float2 npv = {0.f, 0.f};
-    for (;;) {
-        const int n2 = n + stride;
-        const bool next_node = n2 < n_end;
-        const bool first_half = half == 0;
-        if (first_half && next_node) ninfo = a.node_info[n2];
-        tile_add_row(acc, reinterpret_cast<const float *>(Pslot), h);
-        if (HOISTED) {
-#pragma unroll
-            for (int bo = 0; bo < 4; ++bo) acc.b[bo] += x.b[bo];
-        } else {
-            gemm128_h_lds<TERMS, false>(acc, x, w1, lane, a.gelu_a);      // layer 1
-        }
-        if (first_half && next_node) {                   // next node's neighbour list and P row
-            nsrc = __builtin_amdgcn_readfirstlane(ninfo.x);
-            nbase = __builtin_amdgcn_readfirstlane(ninfo.y);
-            nK = __builtin_amdgcn_readfirstlane(ninfo.z);
-            njA = a.E_idx[(size_t)nsrc * 64 + (c < nK ? c : 0)];
-            njB = a.E_idx[(size_t)nsrc * 64 + (32 + c < nK ? 32 + c : 0)];
-            npv = Prows[(size_t)n2 * 64 + lane];
-        }
-        const bool next_half = first_half && K > 32;
-#pragma unroll
-        for (int bo = 0; bo < 4; ++bo) {
-            float bv = bias[bo];
-            asm volatile("" : "+v"(bv));   // or the 64 copies are built once, outside the loop, and spilled
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t2.b[bo][r] = bv;
-        }
-        gemm128_h_lds<TERMS, true, true>(t2, acc, w2, lane, a.gelu_a);    // layer 2 on GELU(layer 1), output transposed
-        {   // edge rows and Q rows of the next tile, in flight during the epilogue
-            const int pn = next_half ? n : (next_node ? n2 : n), ps = next_half ? src : nsrc;
-            const int pe = next_half ? (32 + c < K ? 32 + c : 0) : (c < nK ? c : 0);
-            const int pq = next_half ? base + jB : nbase + njA;
-            tile_load_edge(x, block_of(pn, ps), pe, h);
-            tile_load_row(acc, a.Q + (size_t)pq * HD, h);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tile_gelu(t2, a.gelu_b);
-        const int cnt = K - 32 * half;                   // valid edges of this tile (wave-uniform)
-        if (cnt >= 32) {
-#pragma unroll
-            for (int bo = 0; bo < 4; ++bo) {
-                f32x2 s2 = tile_pair(t2.b[bo], 0);      // packed adds: two partial sums per block
-#pragma unroll
-                for (int r = 2; r < 16; r += 2) s2 += tile_pair(t2.b[bo], r);
-                sum[bo] += s2.x + s2.y;
-            }
-        } else {
-#pragma unroll
-            for (int bo = 0; bo < 4; ++bo) {
-                float s0 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s0 += ((r & 3) + 8 * (r >> 2) + 4 * h < cnt) ? t2.b[bo][r] : 0.f;
-                sum[bo] += s0;
-            }
-        }
-        if (next_half) {
-            half = 1;
-            continue;
-        }
-#pragma unroll
-        for (int bo = 0; bo < 4; ++bo) {
-            const float tot = sum[bo] + __shfl_xor(sum[bo], 32);
-            if (h == 0) a.S[(size_t)n * HD + 32 * bo + c] = tot;
-            sum[bo] = 0.f;
-        }
-        if (!next_node) break;
-        n = n2; src = nsrc; base = nbase; K = nK; jA = njA; jB = njB;
-        Pslot[lane] = npv;
-        half = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Node kernel: one wave = 32 nodes (columns).
-//   MODE_IN : h_V = x_in(x)
-//   MODE_UPD: h_V = mod2(LN(v + FFN(v))),  v = mod1(LN(h_V + (W3 @ S + K b3) / 30))
-// then up to four 128x128 projections of the new h_V for the next edge kernels.
-// ---------------------------------------------------------------------------------------------
 #include "node_args.h"
 
 template <bool MODE_UPD>
@@ -718,35 +489,16 @@ hipError_t codlad_take_attr_error() {
     return e;
 }
 
-// edge_tile_kernels.hip
+// edge_tile_kernels.hip, edge_msg_kernel.hip, edge_upd_kernel.hip
 void launch_edge_tile(int terms, bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st);
+void launch_edge_msg(int terms, const EdgeArgs &ea, hipStream_t st);
+void launch_edge_upd(int terms, const EdgeArgs &ea, hipStream_t st);
 
 template <int TERMS>
 static void launch_edge_h(bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st) {
-    static bool attr_set = false;     // one flag per TERMS instantiation
-    constexpr int MSG_WAVES = 8, UPD_WAVES = 8;
-    const size_t lds_msg = 16 * edge_lds_u4<false, MSG_WAVES>(), lds_upd = 16 * edge_lds_u4<true, UPD_WAVES>();
-    static_assert(16 * edge_lds_u4<true, UPD_WAVES>() <= 160 * 1024, "edge update kernel exceeds the CU's LDS");
-    if (!attr_set) {
-        const void *msg[2] = {reinterpret_cast<const void *>(msg_kernel_h<MSG_WAVES, false, TERMS>),
-                              reinterpret_cast<const void *>(msg_kernel_h<MSG_WAVES, true, TERMS>)};
-        const void *upd[2] = {reinterpret_cast<const void *>(upd_kernel_h<UPD_WAVES, false, TERMS>),
-                              reinterpret_cast<const void *>(upd_kernel_h<UPD_WAVES, true, TERMS>)};
-        for (int i = 0; i < 2; ++i) {
-            set_max_lds(msg[i], lds_msg);
-            set_max_lds(upd[i], lds_upd);
-        }
-        attr_set = true;
-    }
-    const int nw = update ? UPD_WAVES : MSG_WAVES;
-    const bool hoisted = ea.E1 != nullptr;
     if (tile_list) return launch_edge_tile(TERMS, update, ea, tile_list, n_tiles, st);
-    const int groups = (ea.n_nodes + nw - 1) / nw;
-    dim3 grid(groups < num_cu() ? groups : num_cu()), block(nw * 64);
-    if (update && hoisted) hipLaunchKernelGGL((upd_kernel_h<UPD_WAVES, true, TERMS>), grid, block, lds_upd, st, ea);
-    else if (update) hipLaunchKernelGGL((upd_kernel_h<UPD_WAVES, false, TERMS>), grid, block, lds_upd, st, ea);
-    else if (hoisted) hipLaunchKernelGGL((msg_kernel_h<MSG_WAVES, true, TERMS>), grid, block, lds_msg, st, ea);
-    else hipLaunchKernelGGL((msg_kernel_h<MSG_WAVES, false, TERMS>), grid, block, lds_msg, st, ea);
+    if (update) launch_edge_upd(TERMS, ea, st);
+    else launch_edge_msg(TERMS, ea, st);
 }
 
 static void launch_edge(bool update, const EdgeArgs &ea, int precision, hipStream_t st, const int2 *tile_list = nullptr,

@@ -10,14 +10,12 @@ i=0
 while read -r SET; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $SET -d $OUT/p$i --output-format csv -- python3 tools/ablate_edge.py run1 $V > $OUT/p$i.log 2>&1
-  python3 tools/pmc_summary.py $OUT/p$i | grep -A12 "edge_kernel_h" > $OUT/p$i.txt || true
+  python3 tools/pmc_summary.py $OUT/p$i | grep -A14 -E "msg_kernel_h<8, false|upd_kernel_h<8, false" > $OUT/p$i.txt || true
   echo "pass $i done: $SET"
 done <<'SETS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC
 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY
 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL
-TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
-TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum
 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY
 SETS
 cat $OUT/p*.txt

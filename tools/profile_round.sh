@@ -2,28 +2,31 @@
 # The measurements behind profiles/<tag>_*: run on the GPU box from the repo root, `bash tools/profile_round.sh <tag>`.
 # Separate rocprofv3 passes (kernel trace; one --pmc pass per counter group), each bounded by a timeout.
 set -e
-TAG=${1:-r01_final}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+TAG=${1:-r02_final}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 3 --warmup 1 > $OUT/bench_f16x3.json 2> $OUT/bench_f16x3.err
-echo "bench f16x3 done"
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision f16x4 > $OUT/bench_f16x4.json 2>/dev/null
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --precision f32 > $OUT/bench_f32.json 2>/dev/null
-echo "bench f16x4/f32 done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/trace.log 2>&1
+python3 bench.py --steps 3 --warmup 1 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
+echo "bench cfg2 (f16x3 + f32 leg + cpu baseline) done"
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --precision f16x4 > $OUT/bench_cfg2_f16x4.json 2>/dev/null
+for c in cfg3 cfg4share cfg5; do python3 bench.py --steps 2 --warmup 1 --config $c > $OUT/bench_$c.json 2>/dev/null; echo "bench $c done"; done
+python3 tools/small_job_latency.py > $OUT/small_jobs.txt 2>/dev/null
+CODLAD_EDGE_TILE_MAX_NODES=0 CODLAD_NODEQ_MAX_TILES=0 python3 tools/small_job_latency.py > $OUT/small_jobs_round1_kernels.txt 2>/dev/null
+echo "small jobs done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg > $OUT/trace.log 2>&1
 python3 tools/kernel_stats.py $OUT/trace > $OUT/kernel_stats.txt
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
 echo "trace done"
 i=0
 while read -r SET; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg > $OUT/pmc$i.log 2>&1
   python3 tools/pmc_summary.py $OUT/pmc$i > $OUT/pmc$i.txt
   echo "pmc pass $i done: $SET"
 done <<'SETS'
 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU
+GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 FETCH_SIZE
 WRITE_SIZE
 SETS
 cat $OUT/pmc*.txt > $OUT/pmc_summary.txt
-rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
