@@ -284,28 +284,11 @@ def sequence(n_res, seed, force=("GLY", "PRO", "TRP", "HIS", "ARG"), phospho=Fal
 
 
 def make_info(res_idx_full):
-    """(permute, atom_idx, atom_orders) for the interior residues, as built by the
-    reference's traj_to_info (utils/protein_module.py:434-494) from the template tables."""
-    names = [IDX2THR[int(z)] for z in res_idx_full[1:-1]]
-    permute, atom_idx = [], []
-    p_off, a_off = 0, 0
-    for nm in names:
-        core = core_atoms[nm]
-        pdb = PDB_ATOM_ORDER[nm]
-        assert set(core) == set(pdb)
-        permute.append([core.index(a) + p_off for a in pdb])
-        atom_idx.append(np.arange(a_off, a_off + len(pdb)))
-        p_off += len(pdb)
-        a_off += 14
-    orders = np.zeros((10, len(names), 3), dtype=np.int64)
-    orders[:, :, 1] = 1
-    orders[:, :, 2] = 2
-    for r, nm in enumerate(names):
-        for i, trip in enumerate(atom_order_list[nm]):
-            orders[i, r] = trip
-    return (torch.from_numpy(np.concatenate(permute).astype(np.int64)),
-            torch.from_numpy(np.concatenate(atom_idx).astype(np.int64)),
-            torch.from_numpy(orders))
+    """(permute, atom_idx, atom_orders) for the interior residues, as built by the reference's traj_to_info
+    (utils/protein_module.py:434-494): the product builder fed with the atom order a PDB file lists."""
+    from .utils.protein_module import info_from_residues
+    names = [IDX2THR[int(z)] for z in res_idx_full]
+    return info_from_residues(names, [PDB_ATOM_ORDER[nm] for nm in names])[0]
 
 
 def cg_nbr_list(xyz, cutoff=21.0):

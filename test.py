@@ -61,6 +61,7 @@ def load_vae(args, device):
     return vae.to(device).eval()
 
 
+_TOPOLOGY = {}                     # output name -> (residue names, atom names per residue) where known (--save_pdb)
 MAX_FRAMES_PER_BATCH = 96          # reference utils/dataset_module.py:220-226: batch_size = min(n_frames, 96)
 
 
@@ -85,8 +86,11 @@ def iter_batches(args):
             prot = synth.make_protein(L, 1000 + i, n_frames=args.synthetic_frames,
                                       phospho=args.vae_type != "N6")
             plan = chunk_plan(args.synthetic_frames)
+            names = [synth.IDX2THR[int(z)] for z in prot["z_full"]]
             for c, (a, b) in enumerate(plan):
-                yield output_name(f"synthetic_L{L}", c, len(plan)), synth.make_batch(prot, range(a, b)), prot["info"]
+                out = output_name(f"synthetic_L{L}", c, len(plan))
+                _TOPOLOGY[out] = (names, [synth.PDB_ATOM_ORDER[nm] for nm in names])
+                yield out, synth.make_batch(prot, range(a, b)), prot["info"]
         return
     if not args.data_process:
         raise SystemExit("pdb/xtc loading needs mdtraj (out of scope): use --data_process --data_files ... or --synthetic")
@@ -233,6 +237,12 @@ def main(args):
         if evaluation is not None:
             evaluation.report(name, args)
         np.save(os.path.join(save_dir, f"{name}_xyz_recon.npy"), xyz.cpu().numpy())
+        if getattr(args, "save_pdb", False) and name in _TOPOLOGY:
+            # reference test.py:787-796 writes the generated ensemble through mdtraj (.xtc + .pdb); here the multi-model
+            # PDB directly, frames of member 0 first (coordinates in Angstrom)
+            from codlad_amd.utils.protein_module import write_pdb
+            write_pdb(os.path.join(save_dir, f"generated_traj_{name}.pdb"), xyz.reshape(-1, xyz.shape[2], 3).cpu().numpy(),
+                      *_TOPOLOGY[name])
         print(f"{name}: {B} frames x {E} members, L={L}, {xyz.shape[2]} atoms: {dt:.2f}s "
               f"({B * E / dt:.1f} structures/s)", flush=True)
     if world > 1:
@@ -288,4 +298,5 @@ if __name__ == "__main__":
     p.add_argument("--synthetic", action="store_true", help="synthetic PED/PDB/Atlas-shaped proteins")
     p.add_argument("--synthetic_frames", type=int, default=10)
     p.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (no checkpoints ship)")
+    p.add_argument("--save_pdb", action="store_true", help="also write the generated ensemble as a multi-model PDB")
     main(p.parse_args())

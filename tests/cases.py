@@ -207,6 +207,9 @@ def metric_inputs(name):
 FLOW_CASES = {"L46_B2": (46, 2, 12, (0.0, 0.37, 1.0), 8), "L87_B2": (87, 2, 13, (0.5,), 5)}
 
 
+INFO_CASES = {"L30": (30, 91, False), "L87_phospho": (87, 92, True)}        # name -> (n_cg, sequence seed, TPO/SEP allowed)
+
+
 VALIDITY_CASES = {"tight": 0.02, "loose": 0.12, "broken": 0.45}     # name -> coordinate noise of the reconstruction (A)
 
 

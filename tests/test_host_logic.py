@@ -288,3 +288,40 @@ def test_hot_edge_kernels_keep_their_register_budget():
         r = table[name]
         assert r["VGPRs"] <= 256 and r["Occupancy"] == 2, (name, r)
         assert r["ScratchSize"] <= scratch, (name, r)
+
+
+@pytest.mark.parametrize("name", list(cases.INFO_CASES))
+def test_info_tables_match_reference_traj_to_info(name):
+    """codlad_amd.utils.protein_module.info_from_residues against the tables the reference's own traj_to_info built
+    (golden g13; mdtraj stood in for by the pandas table traj_to_info reads from it)."""
+    from codlad_amd.utils.protein_module import info_from_residues
+    n_cg, seed, phospho = cases.INFO_CASES[name]
+    gold = np.load(cases.npz_path(f"g13_info_{name}"))
+    z_full = synth.sequence(n_cg + 2, 2000 + seed, phospho=phospho)
+    names = [synth.IDX2THR[int(z)] for z in z_full]
+    (permute, atom_idx, orders), n = info_from_residues(names, [synth.PDB_ATOM_ORDER[nm] for nm in names])
+    assert n == int(gold["n_cg"]) == n_cg + 2
+    assert np.array_equal(permute.numpy(), gold["permute"]) and np.array_equal(atom_idx.numpy(), gold["atom_idx"])
+    assert np.array_equal(orders.numpy(), gold["atom_orders"])
+    with pytest.raises(ValueError, match="do not match the template"):
+        bad = [list(synth.PDB_ATOM_ORDER[nm]) for nm in names]
+        bad[3] = bad[3][:-1] if len(bad[3]) > 4 else bad[3] + ["XX"]
+        info_from_residues(names, bad)
+
+
+def test_pdb_writer_round_trips_through_the_reader(tmp_path):
+    from codlad_amd.utils.protein_module import info_from_residues, read_pdb_topology, write_pdb
+    z_full = synth.sequence(12, 5)
+    names = [synth.IDX2THR[int(z)] for z in z_full]
+    atoms = [synth.PDB_ATOM_ORDER[nm] for nm in names]
+    n_atoms = sum(len(a) for a in atoms[1:-1])
+    xyz = np.random.Generator(np.random.PCG64(1)).uniform(-50, 50, (3, n_atoms, 3)).astype(np.float32)
+    path = os.path.join(tmp_path, "traj.pdb")
+    write_pdb(path, xyz, names, atoms)
+    r_names, r_atoms, r_xyz = read_pdb_topology(path)
+    assert r_names == names[1:-1] and r_atoms == [list(a) for a in atoms[1:-1]]
+    assert np.allclose(r_xyz, xyz[0], atol=5e-4)                       # 3 decimals in the PDB format
+    text = open(path).read()
+    assert text.count("MODEL ") == 3 and text.count("ENDMDL") == 3
+    info, _ = info_from_residues(["GLY"] + r_names + ["GLY"], [["N", "CA", "C", "O"]] + r_atoms + [["N", "CA", "C", "O"]])
+    assert info[0].numel() == n_atoms

@@ -77,6 +77,38 @@ def save(name, **arrays):
 
 
 # ----------------------------------------------------------------------------
+def g13_info_tables(ref):
+    """Next row 8f-3: the index tables of ic_to_xyz from the reference's own traj_to_info (utils/protein_module.py:434-494).
+    mdtraj is absent; traj_to_info only asks the trajectory for `traj.top.to_dataframe()` (a pandas table with the
+    columns resSeq, chainID, name, resName) and calls get_atomNum, whose result it does not use - a stand-in object
+    provides that table for a synthetic sequence, everything else is the reference's code."""
+    import pandas as pd
+    import utils.protein_module as pm
+    print("g13 info tables (traj_to_info)")
+    for name, (n_cg, seed, phospho) in cases.INFO_CASES.items():
+        z_full = synth.sequence(n_cg + 2, 2000 + seed, phospho=phospho)
+        names = [synth.IDX2THR[int(z)] for z in z_full]
+        rows = [dict(resSeq=10 + r, chainID=0, name=a, resName=nm) for r, nm in enumerate(names)
+                for a in synth.PDB_ATOM_ORDER[nm]]
+        table = pd.DataFrame(rows)
+
+        class _Top:
+            def to_dataframe(self):
+                return table, None
+
+        class _Traj:
+            top = _Top()
+
+        orig = pm.get_atomNum
+        pm.get_atomNum = lambda traj: (np.zeros(len(table), dtype=np.int64), np.arange(len(table)))
+        try:
+            (permute, atom_idx, orders), n = quiet(pm.traj_to_info, _Traj())
+        finally:
+            pm.get_atomNum = orig
+        save(f"g13_info_{name}", permute=permute, atom_idx=atom_idx, atom_orders=orders, n_cg=np.array(n))
+
+
+# ----------------------------------------------------------------------------
 def g12_flow(ref):
     """Next row 8f-4: a flow-matching model (--model fm: W_out has input_size rows, latent_model.py:142-143) evaluated
     at fractional times the way run_sampling's lambda does (test.py:231: model.forward(x_in, t, y1, mask, batch) with
@@ -508,6 +540,7 @@ def main():
     if want("g10"): g10_envelope(ref)
     if want("g11"): g11_validity(ref)
     if want("g12"): g12_flow(ref)
+    if want("g13"): g13_info_tables(ref)
 
 
 if __name__ == "__main__":
