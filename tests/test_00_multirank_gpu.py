@@ -53,21 +53,35 @@ def test_two_rank_job_equals_single_process(tmp_path):
         assert np.array_equal(got[f"xyz_{u}"], whole[u][2].cpu().numpy()), f"unit {u} differs between 2 ranks and 1"
 
 
-@pytest.mark.timeout(900)
-def test_bench_sharded_config_two_ranks():
-    """bench.py --config cfg3 --gpus 2 as the driver launches it (torch.distributed.run), both ranks on cuda:0 over
-    gloo: one JSON line, strong scaling, all 64 structures accounted for."""
+def _bench_two_ranks(extra):
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "1", "--config", "cfg3"]
+           "--warmup", "1"] + extra
     res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=850)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    r = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_sharded_config_two_ranks():
+    """bench.py --config cfg3 --gpus 2 as the driver launches it (torch.distributed.run), both ranks on cuda:0 over
+    gloo: one JSON line, strong scaling, all 64 structures accounted for."""
+    r = _bench_two_ranks(["--config", "cfg3"])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["structures_per_step"] == 64
     assert r["value"] > 0 and 0 < r["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(900)
+def test_bench_default_config_two_ranks():
+    """The driver's N > 1 command on the default configuration (cfg2, weak scaling: one 400-structure replica per rank,
+    weights broadcast, coordinates all-gathered inside the timed region)."""
+    r = _bench_two_ranks([])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["structures_per_step"] == 800
+    assert r["metric"].startswith("sampled all-atom structures/sec") and r["value"] > 0
+    assert "cpu_baseline" not in r and "f32_mfma" not in r          # rank-0, N = 1 only
 
 
 def _cli(extra, tmp_path, ranks=1, timeout=500):
