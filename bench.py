@@ -374,7 +374,8 @@ def main():
                 16 * int(wl.csr[0][-1]) // 2
             roofline = {"bound": "hbm", "achieved": nbytes / t_dec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": nbytes / t_dec / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "cg_graph + vq + dec_init/msg/heads + ic_to_xyz (the whole decode, launch-latency bound)",
+                        "kernel": "cg_graph + vq + dec_init/edge/dense/heads + ic_to_xyz (the whole decode; its largest kernel, "
+                                  "dec_edge_kernel, is fp32-VALU bound: 16 transcendentals + 600 FMA per CG edge)",
                         "launch_ms": t_dec * 1e3, "algorithmic_bytes_per_launch": nbytes}
         else:
             # dominant kernel: layers 1-2 of the encoder message MLP.  Algorithmic 2*(384*128 + 128*128) FLOP per

@@ -1,6 +1,5 @@
-// Decoder tail: de-normalise + VQ lookup, IC decoder message passing,
-// internal coordinates -> Cartesian.  All of it is small (40-wide features), latency/HBM bound:
-// plain FMA kernels, one wave per residue where a reduction over features is needed.
+// Decoder tail (SURVEY.md 8a rows 8 and 10, and the CG graph of 8f-3): de-normalise + VQ lookup, CG neighbour
+// list, internal coordinates -> Cartesian.  Row 9 (the IC decoder) is ic_decoder_kernels.hip.
 #include "common.h"
 #include "../../include/codlad_hip.h"
 
@@ -8,32 +7,47 @@
 // Row 8.  d(z, e) = (|z|^2 + |e|^2) - 2 * dot(z, e), evaluated in exactly the association the
 // reference's CPU path uses so the argmin is bit-identical on identical latents:
 //   |v|^2 = (v0*v0 + v1*v1) + v2*v2 (separately rounded),  dot = fma(z2,e2, fma(z1,e1, z0*e0)).
-// First index wins ties.
+// First index wins ties.  A workgroup = 64 latents x 8 waves: the codebook (with |e|^2) sits in LDS, each
+// wave scans one eighth of it (a broadcast read per code), and wave 0 merges the eight (distance, index)
+// candidates in index order with a strict <, which is the first-minimum rule of the sequential scan.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vq_kernel(const float *x, int n, const float *mean3,
-                                                const float *std3, const float *codebook,
-                                                int n_codes, int64_t *idx, float *z_q,
-                                                float *latent_out) {
-    extern __shared__ __align__(16) float4 code[];  // (e0, e1, e2, |e|^2)
+#define VQ_WAVES 8
+__global__ __launch_bounds__(64 * VQ_WAVES) void vq_kernel(const float *x, int n, const float *mean3,
+                                                          const float *std3, const float *codebook,
+                                                          int n_codes, int64_t *idx, float *z_q,
+                                                          float *latent_out) {
+    extern __shared__ __align__(16) float4 code[];  // (e0, e1, e2, |e|^2) x n_codes, then the merge area
+    float *cand_d = reinterpret_cast<float *>(code + n_codes);
+    int *cand_i = reinterpret_cast<int *>(cand_d + 64 * VQ_WAVES);
     for (int cidx = threadIdx.x; cidx < n_codes; cidx += blockDim.x) {
         const float e0 = codebook[3 * cidx], e1 = codebook[3 * cidx + 1], e2 = codebook[3 * cidx + 2];
         const float se = __fadd_rn(__fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2));
         code[cidx] = make_float4(e0, e1, e2, se);
     }
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float z0 = __fadd_rn(__fmul_rn(x[3 * i], std3[0]), mean3[0]);
-    const float z1 = __fadd_rn(__fmul_rn(x[3 * i + 1], std3[1]), mean3[1]);
-    const float z2 = __fadd_rn(__fmul_rn(x[3 * i + 2], std3[2]), mean3[2]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane, ii = i < n ? i : n - 1;
+    const float z0 = __fadd_rn(__fmul_rn(x[3 * ii], std3[0]), mean3[0]);
+    const float z1 = __fadd_rn(__fmul_rn(x[3 * ii + 1], std3[1]), mean3[1]);
+    const float z2 = __fadd_rn(__fmul_rn(x[3 * ii + 2], std3[2]), mean3[2]);
     const float sz = __fadd_rn(__fadd_rn(__fmul_rn(z0, z0), __fmul_rn(z1, z1)), __fmul_rn(z2, z2));
+    const int per = (n_codes + VQ_WAVES - 1) / VQ_WAVES;
+    const int c0 = wave * per < n_codes ? wave * per : n_codes, c1 = c0 + per < n_codes ? c0 + per : n_codes;
     float best = INFINITY;
     int bi = 0;
-    for (int cidx = 0; cidx < n_codes; ++cidx) {
+    for (int cidx = c0; cidx < c1; ++cidx) {
         const float4 e = code[cidx];
         const float dot = __fmaf_rn(z2, e.z, __fmaf_rn(z1, e.y, __fmul_rn(z0, e.x)));
         const float d = __fsub_rn(__fadd_rn(sz, e.w), __fmul_rn(2.0f, dot));
         if (d < best) { best = d; bi = cidx; }
+    }
+    cand_d[wave * 64 + lane] = best;
+    cand_i[wave * 64 + lane] = bi;
+    __syncthreads();
+    if (wave != 0 || i >= n) return;
+    for (int w = 1; w < VQ_WAVES; ++w) {
+        const float d = cand_d[w * 64 + lane];
+        if (d < best) { best = d; bi = cand_i[w * 64 + lane]; }
     }
     idx[i] = bi;
     const float4 e = code[bi];
@@ -46,161 +60,16 @@ extern "C" int codlad_vq_lookup(const float *x, int n, const float *mean3, const
                                 float *latent_out, void *stream) {
     CODLAD_REQUIRE(x && mean3 && std3 && codebook && idx && z_q, "null pointer");
     CODLAD_REQUIRE(n > 0 && n_codes > 0, "n and n_codes must be positive");
-    const size_t lds = (size_t)n_codes * sizeof(float4);
+    const size_t lds = (size_t)n_codes * sizeof(float4) + 64 * VQ_WAVES * (sizeof(float) + sizeof(int));
     CODLAD_REQUIRE(lds <= 160 * 1024, "codebook does not fit in LDS");
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vq_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { codlad_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(vq_kernel, dim3((n + 255) / 256), dim3(256), lds, (hipStream_t)stream, x, n,
+    hipLaunchKernelGGL(vq_kernel, dim3((n + 63) / 64), dim3(64 * VQ_WAVES), lds, (hipStream_t)stream, x, n,
                        mean3, std3, codebook, n_codes, idx, z_q, latent_out);
     return codlad_check_launch("codlad_vq_lookup");
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row 9.  One wave per residue; lane c holds element c of every (<= 50 wide) feature vector.
-// ---------------------------------------------------------------------------------------------
-#define DF 40
-#define SCR 200  // scratch floats per node: S[0:50] | phiA[50:90] | phiB[90:130] | spare
-
-DEV float swishf(float v) { return v * (1.0f / (1.0f + expf(-v))); }
-
-// y[c] = b[c] + sum_k W[c][k] * x[k]; x[k] lives in lane k.  Valid for lanes c < out_dim.
-DEV float wave_matvec(const float *W, const float *b, int out_dim, int in_dim, float x, int lane) {
-    const int c = lane < out_dim ? lane : 0;
-    float acc = 0.f;
-    for (int k = 0; k < in_dim; ++k) acc = fmaf(__shfl(x, k, 64), W[c * in_dim + k], acc);
-    return acc + b[c];
-}
-
-// nn.Sequential(swish, Linear(.1), swish, Linear(.3)) on a vector spread over lanes
-DEV float wave_seq(const float *w1, const float *b1, int mid, int in_dim, const float *w3,
-                   const float *b3, int out_dim, float x, int lane) {
-    const float hmid = wave_matvec(w1, b1, mid, in_dim, lane < in_dim ? swishf(x) : 0.f, lane);
-    return wave_matvec(w3, b3, out_dim, mid, lane < mid ? swishf(hmid) : 0.f, lane);
-}
-
-__global__ __launch_bounds__(256) void dec_init_kernel(codlad_decoder_weights w, const float *z_q,
-                                                      const int32_t *cg_z, int M, float *scr) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= M) return;
-    const int z = cg_z[n];
-    float s = 0.f;
-    if (lane < 36) {
-        const float *wr = w.map_out_w + lane * 3;  // F.linear: bias + fma chain over 3 inputs
-        s = fmaf(z_q[3 * n + 2], wr[2], fmaf(z_q[3 * n + 1], wr[1], z_q[3 * n] * wr[0])) + w.map_out_b[lane];
-    } else if (lane < DF) {
-        s = w.res_embed[z * 4 + (lane - 36)];
-    }
-    float *sn = scr + (size_t)n * SCR;
-    if (lane < DF) sn[lane] = s;
-    // phi for message block 0: inv_dense = Dense(swish) -> Dense
-    const float t = wave_matvec(w.inv0_w[0], w.inv0_b[0], DF, DF, lane < DF ? s : 0.f, lane);
-    const float phi = wave_matvec(w.inv1_w[0], w.inv1_b[0], DF, DF, lane < DF ? swishf(t) : 0.f, lane);
-    if (lane < DF) sn[50 + lane] = phi;
-}
-
-__global__ __launch_bounds__(256) void dec_msg_kernel(codlad_decoder_weights w, int blk,
-                                                     const float *cg_xyz, const int32_t *csr_ptr,
-                                                     const int32_t *csr_src, int M, float *scr) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= M) return;
-    const int phi_in = 50 + 40 * (blk & 1), phi_out = 50 + 40 * ((blk + 1) & 1);
-    const float xi = cg_xyz[3 * n], yi = cg_xyz[3 * n + 1], zi = cg_xyz[3 * n + 2];
-    const int c = lane < DF ? lane : 0;
-    const float *Wd = w.dist_w[blk] + c * 15;
-    const float bd = w.dist_b[blk][c];
-    const float coef = ((float)((lane < 15 ? lane : 0) + 1) * 3.14159265358979323846f) / 21.0f;
-    float v = 0.f;
-    const int e0 = csr_ptr[n], e1 = csr_ptr[n + 1];
-    for (int e = e0; e < e1; ++e) {
-        const int j = csr_src[e];
-        // preprocess_r (gcn_nn.py:66-70): eps added per component
-        const float rx = cg_xyz[3 * j] - xi, ry = cg_xyz[3 * j + 1] - yi, rz = cg_xyz[3 * j + 2] - zi;
-        const float d = sqrtf(((rx * rx + 1e-8f) + (ry * ry + 1e-8f)) + (rz * rz + 1e-8f));
-        // PainnRadialBasis (gcn_nn.py:231-255): sin(n pi d / cutoff) / d, 0 beyond the cutoff
-        float rbf = d == 0.f ? coef : sinf(coef * d) / d;
-        if (d >= 21.0f) rbf = 0.f;
-        float env = 0.5f * (cosf(3.14159265358979323846f * d / 21.0f) + 1.0f);
-        if (d >= 21.0f) env = 0.f;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 15; ++k) acc = fmaf(__shfl(rbf, k, 64), Wd[k], acc);
-        const float ws = (acc + bd) * env;
-        v += scr[(size_t)j * SCR + phi_in + c] * ws;
-    }
-    // S += dense_blocks[blk](v)
-    float *sn = scr + (size_t)n * SCR;
-    const float upd = wave_seq(w.dense1_w[blk], w.dense1_b[blk], DF, DF, w.dense3_w[blk],
-                               w.dense3_b[blk], DF, v, lane);
-    const float s = (lane < DF ? sn[lane] : 0.f) + upd;
-    if (lane < DF) sn[lane] = s;
-    if (blk < 3) {
-        const float t = wave_matvec(w.inv0_w[blk + 1], w.inv0_b[blk + 1], DF, DF, lane < DF ? s : 0.f, lane);
-        const float phi = wave_matvec(w.inv1_w[blk + 1], w.inv1_b[blk + 1], DF, DF,
-                                      lane < DF ? swishf(t) : 0.f, lane);
-        if (lane < DF) sn[phi_out + lane] = phi;
-    }
-}
-
-__global__ __launch_bounds__(256) void dec_heads_kernel(codlad_decoder_weights w, const int32_t *cg_z,
-                                                       int M, const float *scr, float *ic) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= M) return;
-    const int z = cg_z[n];
-    const float s = lane < DF ? scr[(size_t)n * SCR + lane] : 0.f;
-    const float bb_angle = wave_seq(w.bb_ang1_w, w.bb_ang1_b, 3, DF, w.bb_ang3_w, w.bb_ang3_b, 3, s, lane);
-    // cat([S, bb_angle]) : lanes 40..42 take the three angles
-    float cat = s;
-    for (int k = 0; k < 3; ++k) { const float a = __shfl(bb_angle, k, 64); if (lane == DF + k) cat = a; }
-    const float bb_tors = wave_seq(w.bb_tor1_w, w.bb_tor1_b, 3, DF + 3, w.bb_tor3_w, w.bb_tor3_b, 3, cat, lane);
-    float sc_angle, t;
-    int F;
-    if (w.angle) {
-        sc_angle = wave_seq(w.sc_ang1_w, w.sc_ang1_b, 10, DF, w.sc_ang3_w, w.sc_ang3_b, 10, s, lane);
-        t = s;
-        for (int k = 0; k < 10; ++k) { const float a = __shfl(sc_angle, k, 64); if (lane == DF + k) t = a; }
-        F = DF + 10;
-    } else {
-        sc_angle = lane < 10 ? w.sc_angle_emb[z * 10 + lane] : 0.f;
-        t = s;
-        F = DF;
-    }
-    for (int b = 0; b < 4; ++b) {
-        const float u = wave_seq(w.tor1_w[b], w.tor1_b[b], F, F, w.tor3_w[b], w.tor3_b[b], F, t, lane);
-        t = lane < F ? t + u : 0.f;
-    }
-    const float sc_tors = wave_seq(w.fin1_w, w.fin1_b, 10, F, w.fin3_w, w.fin3_b, 10, t, lane);
-    float *o = ic + (size_t)n * 39;
-    if (lane < 3) {
-        o[lane * 3 + 0] = w.bb_dist[z * 3 + lane];
-        o[lane * 3 + 1] = bb_angle;
-        o[lane * 3 + 2] = bb_tors;
-    }
-    if (lane < 10) {
-        o[(3 + lane) * 3 + 0] = w.sc_dist[z * 10 + lane];
-        o[(3 + lane) * 3 + 1] = sc_angle;
-        o[(3 + lane) * 3 + 2] = sc_tors;
-    }
-}
-
-extern "C" int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_q,
-                                const int32_t *cg_z, const float *cg_xyz, const int32_t *csr_ptr,
-                                const int32_t *csr_src, int M, float *scratch, float *ic_out,
-                                void *stream) {
-    CODLAD_REQUIRE(w && z_q && cg_z && cg_xyz && csr_ptr && csr_src && scratch && ic_out, "null pointer");
-    CODLAD_REQUIRE(M > 0, "M must be positive");
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((M + 3) / 4), block(256);
-    hipLaunchKernelGGL(dec_init_kernel, grid, block, 0, st, *w, z_q, cg_z, M, scratch);
-    for (int blk = 0; blk < 4; ++blk)
-        hipLaunchKernelGGL(dec_msg_kernel, grid, block, 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
-    hipLaunchKernelGGL(dec_heads_kernel, grid, block, 0, st, *w, cg_z, M, scratch, ic_out);
-    return codlad_check_launch("codlad_ic_decode");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,291 @@
+// Row 9: the IC decoder, VAE.decoder = map_out + IC_Decoder[_angle].forward
+// (reference models/vae_model.py:759-764, 375-412, 467-503; Dense / radial basis / envelope: models/gcn_nn.py).
+//
+// Two kinds of kernel, by what the work is made of:
+//  * per-residue dense layers (40..53-wide Linear + swish chains): one LANE per residue, 64 residues per
+//    workgroup, the outputs of a layer dealt to its 4 waves.  A lane keeps the layer's input vector in registers,
+//    the weight row of the output being produced is wave-uniform and comes through the scalar cache (constant
+//    address space -> s_load), so a product is one v_fmac with an SGPR operand and nothing is shuffled between
+//    lanes.  Vectors pass from layer to layer through LDS columns, activated once by the wave that produced them.
+//  * the distance-conditioned messages (per directed CG edge: 15 sines, a 15 -> 40 Linear, an envelope, and a
+//    40-wide multiply-accumulate into the receiving residue): one WAVE per receiving residue.  Per chunk of 64
+//    incoming edges, lane = edge evaluates the radial basis and the Linear (again with scalar weight rows) and
+//    leaves the 40 filter values in LDS; then lane = feature walks the edges in CSR order, multiplies by the
+//    sender's row (one coalesced 160-byte read) and accumulates.
+// Every sum keeps the order of the reference's ops (fma chain over k, then + bias; edges in scatter order), so
+// results do not depend on which residues share a launch.
+//
+// Scratch (caller's float [M][200], opaque): S^T [40][M] | V^T [40][M] | phi_a [M][40] | phi_b [M][40].
+#include "common.h"
+#include "../../include/codlad_hip.h"
+
+#define DF 40
+#define PI_F 3.14159265358979323846f
+#define CG_CUTOFF 21.0f
+
+typedef const __attribute__((address_space(4))) float *kfloat_p;
+DEV kfloat_p as_uniform(const float *p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (kfloat_p)p;
+#pragma clang diagnostic pop
+}
+
+DEV float swishf(float v) { return v * (1.0f / (1.0f + expf(-v))); }
+
+// One Linear layer for the 64 residues of a workgroup, its outputs dealt round-robin to the 4 waves:
+// emit(c, b[c] + sum_k W[c][k] * in[k]) for c = wave, wave + 4, ... < out_dim.  `in`: this lane's LDS column
+// (stride 64 floats), already activated if the layer's input is.  The caller separates layers with __syncthreads().
+template <int IN, typename Emit>
+DEV void wg_dense(const float *W, const float *b, int out_dim, const float *in, int wave, Emit emit) {
+    float x[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = in[k * 64];
+    kfloat_p Wk = as_uniform(W), bk = as_uniform(b);
+    for (int c = wave; c < out_dim; c += 4) {
+        kfloat_p wr = Wk + c * IN;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < IN; ++k) acc = fmaf(x[k], wr[k], acc);
+        emit(c, acc + bk[c]);
+    }
+}
+
+struct Scratch {
+    float *S, *V, *phi[2];
+};
+DEV Scratch scratch_of(float *scr, int M) {
+    Scratch s;
+    s.S = scr;
+    s.V = scr + (size_t)DF * M;
+    s.phi[0] = scr + (size_t)2 * DF * M;
+    s.phi[1] = scr + (size_t)3 * DF * M;
+    return s;
+}
+
+// phi of a message block: inv_dense = Dense -> swish -> Dense on the raw state  (vae_model.py:360-363)
+DEV void write_phi(const codlad_decoder_weights &w, int blk, const float *s_col, float *t_col, float *phi, int n,
+                   bool active, int wave) {
+    wg_dense<DF>(w.inv0_w[blk], w.inv0_b[blk], DF, s_col, wave, [&](int c, float v) { t_col[c * 64] = swishf(v); });
+    __syncthreads();
+    wg_dense<DF>(w.inv1_w[blk], w.inv1_b[blk], DF, t_col, wave, [&](int c, float v) {
+        if (active) phi[(size_t)n * DF + c] = v;
+    });
+}
+
+// S = cat(map_out(z_q), res_embed[z])  (vae_model.py:759-764, 380-383), phi for block 0
+__global__ __launch_bounds__(256) void dec_init_kernel(codlad_decoder_weights w, const float *z_q,
+                                                      const int32_t *cg_z, int M, float *scr) {
+    __shared__ float col[2 * DF][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = blockIdx.x * 64 + lane;
+    const bool active = n < M;
+    const int nn = active ? n : M - 1;
+    const Scratch sc = scratch_of(scr, M);
+    float *s_col = &col[0][lane], *t_col = &col[DF][lane];
+    const int z = cg_z[nn];
+    const float q0 = z_q[3 * nn], q1 = z_q[3 * nn + 1], q2 = z_q[3 * nn + 2];
+    kfloat_p mw = as_uniform(w.map_out_w), mb = as_uniform(w.map_out_b);
+    for (int c = wave; c < DF; c += 4) {
+        float s;
+        if (c < 36) s = fmaf(q2, mw[3 * c + 2], fmaf(q1, mw[3 * c + 1], q0 * mw[3 * c])) + mb[c];   // F.linear
+        else s = w.res_embed[z * 4 + (c - 36)];
+        s_col[c * 64] = s;
+        if (active) sc.S[(size_t)c * M + n] = s;
+    }
+    __syncthreads();
+    write_phi(w, 0, s_col, t_col, sc.phi[0], n, active, wave);
+}
+
+// a / d the way the compiler's IEEE expansion computes it (v_rcp, one refinement of the reciprocal, two of the
+// quotient) with the reciprocal shared by the 15 numerators; d is a distance >= 1.7e-4, |a| <= 1: no range scaling.
+DEV float refined_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+DEV float div_by(float a, float d, float r) {
+    float q = a * r;
+    q = fmaf(fmaf(-d, q, a), r, q);
+    return fmaf(fmaf(-d, q, a), r, q);
+}
+
+// V[n] = sum over incoming edges (j -> n) of phi_j * (dist_embed(rbf(d)) * envelope(d))   (vae_model.py:483-488)
+#define WS_STRIDE 41
+__global__ __launch_bounds__(256) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
+                                                      const int32_t *csr_ptr, const int32_t *csr_src, int M,
+                                                      float *scr) {
+    __shared__ float filt[4][64 * WS_STRIDE];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (n >= M) return;                                // waves are independent: no workgroup barrier below
+    const Scratch sc = scratch_of(scr, M);
+    const float *phi_in = sc.phi[blk & 1];
+    float *my = filt[wave];
+    const float xi = cg_xyz[3 * n], yi = cg_xyz[3 * n + 1], zi = cg_xyz[3 * n + 2];
+    const int c = lane < DF ? lane : 0;
+    kfloat_p Wd = as_uniform(w.dist_w[blk]), bd = as_uniform(w.dist_b[blk]);
+    float v = 0.f;
+    const int e0 = __builtin_amdgcn_readfirstlane(csr_ptr[n]), e1 = __builtin_amdgcn_readfirstlane(csr_ptr[n + 1]);
+    for (int base = e0; base < e1; base += 64) {
+        const int cnt = e1 - base < 64 ? e1 - base : 64;
+        int j = 0;
+        if (lane < cnt) {
+            j = csr_src[base + lane];
+            // preprocess_r (gcn_nn.py:66-70): eps added per component
+            const float rx = cg_xyz[3 * j] - xi, ry = cg_xyz[3 * j + 1] - yi, rz = cg_xyz[3 * j + 2] - zi;
+            const float d = sqrtf(((rx * rx + 1e-8f) + (ry * ry + 1e-8f)) + (rz * rz + 1e-8f));
+            // CosineEnvelope and PainnRadialBasis (gcn_nn.py:231-255): sin(n pi d / cutoff) / d, 0 beyond the cutoff
+            float env = 0.5f * (cosf(PI_F * d / CG_CUTOFF) + 1.0f);
+            if (d >= CG_CUTOFF) env = 0.f;
+            const float rd = refined_rcp(d);
+            float rbf[15];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const float coef = ((float)(k + 1) * PI_F) / CG_CUTOFF;
+                rbf[k] = div_by(sinf(coef * d), d, rd);
+                if (d >= CG_CUTOFF) rbf[k] = 0.f;
+            }
+            for (int f = 0; f < DF; ++f) {
+                kfloat_p wr = Wd + f * 15;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) acc = fmaf(rbf[k], wr[k], acc);
+                my[lane * WS_STRIDE + f] = (acc + bd[f]) * env;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int e = 0;
+        for (; e + 8 <= cnt; e += 8) {                  // eight sender rows in flight, summed in edge order
+            float ph[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *row = phi_in + (size_t)__builtin_amdgcn_readlane(j, e + u) * DF;
+                ph[u] = row[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += ph[u] * my[(e + u) * WS_STRIDE + c];
+        }
+        for (; e < cnt; ++e) {
+            const float *row = phi_in + (size_t)__builtin_amdgcn_readlane(j, e) * DF;
+            v += row[c] * my[e * WS_STRIDE + c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane < DF) sc.V[(size_t)lane * M + n] = v;
+}
+
+// S += dense_blocks[blk](V)  (Sequential(swish, Linear, swish, Linear), vae_model.py:365-369, 489), phi for blk + 1
+__global__ __launch_bounds__(256) void dec_dense_kernel(codlad_decoder_weights w, int blk, int M, float *scr) {
+    __shared__ float col[3 * DF][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = blockIdx.x * 64 + lane;
+    const bool active = n < M;
+    const int nn = active ? n : M - 1;
+    const Scratch sc = scratch_of(scr, M);
+    float *a_col = &col[0][lane], *t_col = &col[DF][lane], *s_col = &col[2 * DF][lane];
+    for (int c = wave; c < DF; c += 4) a_col[c * 64] = swishf(sc.V[(size_t)c * M + nn]);
+    __syncthreads();
+    wg_dense<DF>(w.dense1_w[blk], w.dense1_b[blk], DF, a_col, wave, [&](int c, float v) { t_col[c * 64] = swishf(v); });
+    __syncthreads();
+    wg_dense<DF>(w.dense3_w[blk], w.dense3_b[blk], DF, t_col, wave, [&](int c, float v) {
+        const float s = sc.S[(size_t)c * M + nn] + v;
+        s_col[c * 64] = s;
+        if (active) sc.S[(size_t)c * M + n] = s;
+    });
+    if (blk == 3) return;
+    __syncthreads();
+    write_phi(w, blk + 1, s_col, a_col, sc.phi[(blk + 1) & 1], n, active, wave);
+}
+
+// The output heads (vae_model.py:393-412 / 490-503): backbone angles and torsions, side-chain angles
+// (embedding or head), the four residual torsion blocks and the final torsion head; bond lengths from tables.
+// Every head is Sequential(swish, Linear, swish, Linear): `xs` holds swish of the running state, refreshed by the
+// wave that updates a row.
+template <bool ANGLE>
+__global__ __launch_bounds__(256) void dec_heads_kernel(codlad_decoder_weights w, const int32_t *cg_z, int M,
+                                                       const float *S, float *ic) {
+    constexpr int F = ANGLE ? DF + 10 : DF;
+    // rows: xs 0..55 | t 56..111 | u 112..167 | small 168..199
+    __shared__ float col[200][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = blockIdx.x * 64 + lane;
+    const bool active = n < M;
+    const int nn = active ? n : M - 1;
+    float *xs = &col[0][lane], *t_col = &col[56][lane], *u_col = &col[112][lane], *sm = &col[168][lane];
+    float *bb_angle = sm + 3 * 64, *bb_tors = sm + 9 * 64, *sc_angle = sm + 12 * 64, *sc_tors = sm + 22 * 64;
+    const int z = cg_z[nn];
+    for (int c = wave; c < DF; c += 4) {
+        const float s = S[(size_t)c * M + nn];
+        t_col[c * 64] = s;
+        xs[c * 64] = swishf(s);
+    }
+    __syncthreads();
+    wg_dense<DF>(w.bb_ang1_w, w.bb_ang1_b, 3, xs, wave, [&](int c, float v) { sm[c * 64] = swishf(v); });
+    __syncthreads();
+    wg_dense<3>(w.bb_ang3_w, w.bb_ang3_b, 3, sm, wave, [&](int c, float v) {
+        bb_angle[c * 64] = v;
+        xs[(DF + c) * 64] = swishf(v);                                             // cat([S, bb_angle])
+    });
+    __syncthreads();
+    wg_dense<DF + 3>(w.bb_tor1_w, w.bb_tor1_b, 3, xs, wave, [&](int c, float v) { sm[(6 + c) * 64] = swishf(v); });
+    __syncthreads();
+    wg_dense<3>(w.bb_tor3_w, w.bb_tor3_b, 3, sm + 6 * 64, wave, [&](int c, float v) { bb_tors[c * 64] = v; });
+    if (ANGLE) {
+        wg_dense<DF>(w.sc_ang1_w, w.sc_ang1_b, 10, xs, wave, [&](int c, float v) { u_col[c * 64] = swishf(v); });
+        __syncthreads();
+        wg_dense<10>(w.sc_ang3_w, w.sc_ang3_b, 10, u_col, wave, [&](int c, float v) {
+            sc_angle[c * 64] = v;
+            t_col[(DF + c) * 64] = v;                                              // cat([S, sc_angle])
+            xs[(DF + c) * 64] = swishf(v);
+        });
+    } else {
+        for (int k = wave; k < 10; k += 4) sc_angle[k * 64] = w.sc_angle_emb[z * 10 + k];
+    }
+    __syncthreads();
+    for (int b = 0; b < 4; ++b) {
+        wg_dense<F>(w.tor1_w[b], w.tor1_b[b], F, xs, wave, [&](int c, float v) { u_col[c * 64] = swishf(v); });
+        __syncthreads();
+        wg_dense<F>(w.tor3_w[b], w.tor3_b[b], F, u_col, wave, [&](int c, float v) {
+            const float t = t_col[c * 64] + v;
+            t_col[c * 64] = t;
+            xs[c * 64] = swishf(t);
+        });
+        __syncthreads();
+    }
+    wg_dense<F>(w.fin1_w, w.fin1_b, 10, xs, wave, [&](int c, float v) { u_col[c * 64] = swishf(v); });
+    __syncthreads();
+    wg_dense<10>(w.fin3_w, w.fin3_b, 10, u_col, wave, [&](int c, float v) { sc_tors[c * 64] = v; });
+    __syncthreads();
+    if (!active) return;
+    float *o = ic + (size_t)n * 39;
+    for (int k = wave; k < 13; k += 4) {
+        if (k < 3) {
+            o[k * 3 + 0] = w.bb_dist[z * 3 + k];
+            o[k * 3 + 1] = bb_angle[k * 64];
+            o[k * 3 + 2] = bb_tors[k * 64];
+        } else {
+            o[k * 3 + 0] = w.sc_dist[z * 10 + (k - 3)];
+            o[k * 3 + 1] = sc_angle[(k - 3) * 64];
+            o[k * 3 + 2] = sc_tors[(k - 3) * 64];
+        }
+    }
+}
+
+extern "C" int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_q,
+                                const int32_t *cg_z, const float *cg_xyz, const int32_t *csr_ptr,
+                                const int32_t *csr_src, int M, float *scratch, float *ic_out,
+                                void *stream) {
+    CODLAD_REQUIRE(w && z_q && cg_z && cg_xyz && csr_ptr && csr_src && scratch && ic_out, "null pointer");
+    CODLAD_REQUIRE(M > 0, "M must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 per_lane((M + 63) / 64), per_wave((M + 3) / 4), block(256);
+    hipLaunchKernelGGL(dec_init_kernel, per_lane, block, 0, st, *w, z_q, cg_z, M, scratch);
+    for (int blk = 0; blk < 4; ++blk) {
+        hipLaunchKernelGGL(dec_edge_kernel, per_wave, block, 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
+        hipLaunchKernelGGL(dec_dense_kernel, per_lane, block, 0, st, *w, blk, M, scratch);
+    }
+    if (w->angle) hipLaunchKernelGGL(dec_heads_kernel<true>, per_lane, block, 0, st, *w, cg_z, M, scratch, ic_out);
+    else hipLaunchKernelGGL(dec_heads_kernel<false>, per_lane, block, 0, st, *w, cg_z, M, scratch, ic_out);
+    return codlad_check_launch("codlad_ic_decode");
+}
