@@ -24,6 +24,7 @@ MSG = "edge_msg_kernel.hip"
 XLOAD = "tile_load_edge(x, rows, colc, h);                          // layer-1 operand and residual"
 QLOAD = "tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);"
 STORE = "            if (valid) tile_store_edge(x, out_rows, col, h);"
+SPAN = "    const NodeSpan span = wave_node_span(a.n_nodes, NWAVES, wave);\n"
 NOSTORE = "            if (valid && x.b[0][0] == 12345.f) tile_store_edge(x, out_rows, col, h);"
 # name -> (extra flags, [(file, old, new), ...])
 VARIANTS = {
@@ -67,6 +68,13 @@ VARIANTS = {
                    "        if (ks + 1 < KS0 + NKS && (bo & 1) == 0) {\n            split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);\n            split_pair<GELU_IN>(xn, in, ks + 1, bo + 1, gk);\n        }\n        mfma_f16<TERMS, TRANSPOSED>(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);")]),
     # message kernel
     "msg_noepi": ([], [(MSG, "        tile_gelu(t2, a.gelu_b);\n", "")]),
+    # start the second wave of every SIMD (and, _wc, the workgroups) a fraction of a tile period late: identical waves
+    # that start together ask for memory together for the whole launch (units of s_sleep 127 = 8 128 cycles ~ 4.3 us)
+    "upd_stag_w": ([], [(UPD, SPAN, SPAN + "    for (int i = 0; i < (wave >= 4 ? 3 : 0); ++i) __builtin_amdgcn_s_sleep(127);\n")]),
+    "upd_stag_wc": ([], [(UPD, SPAN, SPAN + "    for (int i = 0; i < (wave >= 4 ? 3 : 0) + (int)(blockIdx.x & 3); ++i) __builtin_amdgcn_s_sleep(127);\n")]),
+    "upd_stag_fine": ([], [(UPD, SPAN, SPAN + "    for (int i = 0; i < (int)((wave * 37 + blockIdx.x * 11) % 48); ++i) __builtin_amdgcn_s_sleep(15);\n")]),
+    "msg_stag_w": ([], [(MSG, SPAN, SPAN + "    for (int i = 0; i < (wave >= 4 ? 2 : 0); ++i) __builtin_amdgcn_s_sleep(127);\n")]),
+    "msg_stag_fine": ([], [(MSG, SPAN, SPAN + "    for (int i = 0; i < (int)((wave * 37 + blockIdx.x * 11) % 32); ++i) __builtin_amdgcn_s_sleep(15);\n")]),
     "msg_prio": ([], [(MSG, "    const int h = lane >> 5, c = lane & 31;\n    const NodeSpan span", "    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    const int h = lane >> 5, c = lane & 31;\n    const NodeSpan span")]),
 }
 
