@@ -162,10 +162,11 @@ def test_denoiser_forward(den, sd, name):
         assert rel_err(job.hV.cpu().view(B, L, 128), gold["dec2_hV"]) < 1e-5
 
 
-@pytest.mark.parametrize("L", [5, 31, 32, 33, 63, 64, 65, 200, 505])
+@pytest.mark.parametrize("L", [5, 31, 32, 33, 63, 64, 65, 200, 505, 2048])
 def test_denoiser_forward_edge_lengths(den, sd, L):
     """Tile boundaries of the kernels: K = L < 32 (one partly filled column tile), 32/33 (second tile
-    empty / one column), 63/64/65 (K saturates at 64), and the longest Atlas test protein (505)."""
+    empty / one column), 63/64/65 (K saturates at 64), the longest Atlas test protein (505), and a chain four times
+    that (the k-NN selection walks a 2 048-entry distance row per node)."""
     prot = synth.make_protein(L, 70 + L, n_frames=1)
     batch = synth.make_batch(prot)
     x = synth.gaussian((1, L, 3), 5)
@@ -177,6 +178,15 @@ def test_denoiser_forward_edge_lengths(den, sd, L):
     ref = oden.forward(sd, x, t, cg_xyz, cg_z, m)
     assert bool(torch.isfinite(out).all())
     assert rel_err(out, ref) < 1e-5
+
+
+def test_chain_longer_than_the_lds_distance_row_is_refused(den):
+    """The k-NN selection keeps a node's distances to its whole chain in LDS; a chain that does not fit (beyond
+    ~21 k residues) is an error code from the C ABI, not a wrong neighbour list."""
+    L = 30000
+    xyz = synth.gaussian((L, 3), 5) * 60.0
+    with pytest.raises(RuntimeError, match="too long"):
+        den.prepare_structures([xyz], [torch.zeros(L, dtype=torch.long)])
 
 
 def test_ensemble_members_share_structure(den, sd):
