@@ -75,6 +75,10 @@ VARIANTS = {
     "upd_stag_fine": ([], [(UPD, SPAN, SPAN + "    for (int i = 0; i < (int)((wave * 37 + blockIdx.x * 11) % 48); ++i) __builtin_amdgcn_s_sleep(15);\n")]),
     "msg_stag_w": ([], [(MSG, SPAN, SPAN + "    for (int i = 0; i < (wave >= 4 ? 2 : 0); ++i) __builtin_amdgcn_s_sleep(127);\n")]),
     "msg_stag_fine": ([], [(MSG, SPAN, SPAN + "    for (int i = 0; i < (int)((wave * 37 + blockIdx.x * 11) % 32); ++i) __builtin_amdgcn_s_sleep(15);\n")]),
+    # half / none of the weight-fragment reads from LDS (stale fragments reused): what do the 64 KB of LDS reads per
+    # contraction and wave cost in time and in power?
+    "half_lds": ([], [("common.h", "        if (g + 2 < NG) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];", "        if (g + 2 < NG && (g & 1) == 0) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];")]),
+    "no_lds": ([], [("common.h", "        if (g + 2 < NG) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];", "        if (g + 2 < NG && g < 1) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];")]),
     "msg_prio": ([], [(MSG, "    const int h = lane >> 5, c = lane & 31;\n    const NodeSpan span", "    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    const int h = lane >> 5, c = lane & 31;\n    const NodeSpan span")]),
 }
 
