@@ -48,7 +48,10 @@ def gather_coordinates(xyz_list, world_size):
     """All-gather a rank's coordinate tensors.  Ranks may hold different numbers of atoms, so each
     tensor list is flattened to one buffer, padded to the largest rank's size and trimmed after.
     Returns a list (per rank) of flat fp32 tensors."""
-    flat = torch.cat([x.reshape(-1) for x in xyz_list]) if len(xyz_list) else torch.zeros(0)
+    if len(xyz_list):
+        flat = torch.cat([x.reshape(-1) for x in xyz_list])
+    else:       # a rank without units still takes part; RCCL wants its (empty) buffer on the device
+        flat = torch.zeros(0, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     flat = _stage(flat)
     n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
     sizes = [torch.zeros_like(n) for _ in range(world_size)]
