@@ -8,7 +8,7 @@
 //    address space -> s_load), so a product is one v_fmac with an SGPR operand and nothing is shuffled between
 //    lanes.  Vectors pass from layer to layer through LDS columns, activated once by the wave that produced them.
 //  * the distance-conditioned messages (per directed CG edge: 15 sines, a 15 -> 40 Linear, an envelope, and a
-//    40-wide multiply-accumulate into the receiving residue): one WAVE per receiving residue.  Per chunk of 64
+//    40-wide multiply-accumulate into the receiving residue): one WAVE (= one workgroup) per receiving residue.  Per chunk of 64
 //    incoming edges, lane = edge evaluates the radial basis and the Linear (again with scalar weight rows) and
 //    leaves the 40 filter values in LDS; then lane = feature walks the edges in CSR order, multiplies by the
 //    sender's row (one coalesced 160-byte read) and accumulates.
@@ -110,12 +110,15 @@ DEV float div_by(float a, float d, float r) {
 
 // V[n] = sum over incoming edges (j -> n) of phi_j * (dist_embed(rbf(d)) * envelope(d))   (vae_model.py:483-488)
 #define WS_STRIDE 41
-__global__ __launch_bounds__(256) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
+#ifndef EDGE_WAVES
+#define EDGE_WAVES 1   // receivers per workgroup: 1 lets 15 waves share a CU's LDS (cfg 5: 1.04 ms against 1.15 with 4)
+#endif
+__global__ __launch_bounds__(64 * EDGE_WAVES) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
                                                       const int32_t *csr_ptr, const int32_t *csr_src, int M,
                                                       float *scr) {
-    __shared__ float filt[4][64 * WS_STRIDE];
+    __shared__ float filt[EDGE_WAVES][64 * WS_STRIDE];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * EDGE_WAVES + wave);
     if (n >= M) return;                                // waves are independent: no workgroup barrier below
     const Scratch sc = scratch_of(scr, M);
     const float *phi_in = sc.phi[blk & 1];
@@ -279,10 +282,10 @@ extern "C" int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_
     CODLAD_REQUIRE(w && z_q && cg_z && cg_xyz && csr_ptr && csr_src && scratch && ic_out, "null pointer");
     CODLAD_REQUIRE(M > 0, "M must be positive");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 per_lane((M + 63) / 64), per_wave((M + 3) / 4), block(256);
+    const dim3 per_lane((M + 63) / 64), per_wave((M + EDGE_WAVES - 1) / EDGE_WAVES), block(256);
     hipLaunchKernelGGL(dec_init_kernel, per_lane, block, 0, st, *w, z_q, cg_z, M, scratch);
     for (int blk = 0; blk < 4; ++blk) {
-        hipLaunchKernelGGL(dec_edge_kernel, per_wave, block, 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
+        hipLaunchKernelGGL(dec_edge_kernel, per_wave, dim3(64 * EDGE_WAVES), 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
         hipLaunchKernelGGL(dec_dense_kernel, per_lane, block, 0, st, *w, blk, M, scratch);
     }
     if (w->angle) hipLaunchKernelGGL(dec_heads_kernel<true>, per_lane, block, 0, st, *w, cg_z, M, scratch, ic_out);
