@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 7   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 8   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -76,6 +76,8 @@ class MetricInputs(C.Structure):
 
 _SIGS = {
     "codlad_abi_version": (C.c_int, []),
+    "codlad_probe_edge_launches": (C.c_int, [C.c_int]),
+    "codlad_probe_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "codlad_metrics_scratch_bytes": (C.c_int, []),
     "codlad_eval_metrics": (C.c_int, [C.POINTER(MetricInputs), P, P, P]),
     "codlad_bond_graph_counts": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_float, P, P]),

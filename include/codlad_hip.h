@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 7
+#define CODLAD_ABI_VERSION 8
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -290,6 +290,14 @@ int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *order
 #define CODLAD_OPT_LOOP_GRAPH_MAX_NODES 2
 #define CODLAD_N_OPTIONS 4
 int codlad_set_option(int option, int value);
+
+/* Measurement aid for bench.py (not part of the reference's interface): while enabled, every edge-kernel launch made
+ * by codlad_denoiser_forward / codlad_sample_loop is bracketed by a pair of HIP events on its stream (the first 4096
+ * launches after enabling; enabling clears earlier records).  codlad_probe_read waits for the recorded events and
+ * returns how many launches of `kind` were recorded (0 message, 1 edge update, +2 = the hoisted layer-0 variant) with
+ * their summed duration in *total_ms; negative = error.  Not thread-safe; one stream at a time. */
+int codlad_probe_edge_launches(int enable);
+int codlad_probe_read(int kind, double *total_ms);
 
 /* Measurement hook: ONE launch of the message kernel (which = 0) or the edge-update kernel
  * (which = 1) of encoder layer `layer` (0 or 1) on a job whose workspace holds the state of a
