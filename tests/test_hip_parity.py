@@ -191,6 +191,29 @@ def test_chain_longer_than_the_lds_distance_row_is_refused(den):
         den.prepare_structures([xyz], [torch.zeros(L, dtype=torch.long)])
 
 
+def test_edge_launch_probe_counts_the_launches_of_a_forward(den):
+    """bench.py's measurement aid: with the probe on, one forward records 6 message and 3 edge-update launches (the
+    layer-0 pair as the hoisted kind when the step-invariant terms are given), each with a positive duration."""
+    import ctypes as C
+    from codlad_amd import _lib
+    lib = _lib.lib()
+    prot = synth.make_protein(70, 9, n_frames=2)
+    st = structures_of(den, prot)
+    job = den.make_job(st, [0, 1, 1])
+    x = synth.gaussian((job.n_nodes, 3), 2).to(DEV)
+    lib.codlad_probe_edge_launches(1)
+    den.forward(job, x, 10)
+    lib.codlad_probe_edge_launches(0)
+    den.forward(job, x, 10)                      # not recorded
+    got = {}
+    for kind in range(4):
+        total = C.c_double(0.0)
+        got[kind] = (lib.codlad_probe_read(kind, C.byref(total)), total.value)
+    hoisted = st.E1 is not None
+    assert [got[k][0] for k in range(4)] == ([5, 2, 1, 1] if hoisted else [6, 3, 0, 0])
+    assert all(ms > 0 for n, ms in got.values() if n)
+
+
 def test_ensemble_members_share_structure(den, sd):
     """Two samples on ONE structure == the same two samples on two copies of it."""
     L, B, seed = cases.DENOISER_CASES["L46_B2"]
