@@ -89,19 +89,22 @@ DEV void tile_store_row(const Tile &t, float *row, int h) {
                                                 t.b[bo][4 * q + 2], t.b[bo][4 * q + 3]);
 }
 
-// Edge state (h_E0, E1, h_E) in HBM, per node one block of 64 edges x 128 features stored
-// "chunk-major": [32 chunks of 4 features][64 edges][4 floats].  A lane owns an edge (column), so
-// with one row per edge every wave instruction touched 64 separate lines; in this order the 16
-// bytes of neighbouring lanes are neighbours in memory and an instruction covers two contiguous
-// 512-byte runs (lanes 0-31: chunk o, lanes 32-63: chunk o+1).
+// Edge state (h_E0, E1, h_E) in HBM, per node one block of 64 edges x 128 features stored half by half and
+// "chunk-major" within a half: [2 halves of 32 edges][32 chunks of 4 features][32 edges][4 floats].  A lane owns an
+// edge (column), so with one row per edge every wave instruction touched 64 separate lines; in this order the 16
+// bytes of neighbouring lanes are neighbours in memory, an instruction covers one contiguous kilobyte (lanes 0-31:
+// chunk o, lanes 32-63: chunk o+1) and the 16 instructions of a 32-edge tile cover 16 contiguous KB (round 2; with
+// all 64 edges of a chunk together a tile was 32 runs of 512 B at a 1 KB stride: 3 % slower when an edge kernel is
+// launched back to back, no measurable difference inside the job).
 #define EDGE_BLOCK (64 * 128)
+#define EDGE_F4(e) (((e) & 31) + ((e) >> 5) * 1024)   // float4 index of edge e's first chunk; chunk stride 32
 DEV void tile_load_edge(Tile &t, const float *block, int e, int h) {
-    const float4 *p = reinterpret_cast<const float4 *>(block) + e;
+    const float4 *p = reinterpret_cast<const float4 *>(block) + EDGE_F4(e);
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 v = p[(8 * bo + 2 * q + h) * 64];
+            float4 v = p[(8 * bo + 2 * q + h) * 32];
             t.b[bo][4 * q + 0] = v.x;
             t.b[bo][4 * q + 1] = v.y;
             t.b[bo][4 * q + 2] = v.z;
@@ -110,12 +113,12 @@ DEV void tile_load_edge(Tile &t, const float *block, int e, int h) {
 }
 
 DEV void tile_add_edge(Tile &t, const float *block, int e, int h) {
-    const float4 *p = reinterpret_cast<const float4 *>(block) + e;
+    const float4 *p = reinterpret_cast<const float4 *>(block) + EDGE_F4(e);
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 v = p[(8 * bo + 2 * q + h) * 64];
+            float4 v = p[(8 * bo + 2 * q + h) * 32];
             t.b[bo][4 * q + 0] += v.x;
             t.b[bo][4 * q + 1] += v.y;
             t.b[bo][4 * q + 2] += v.z;
@@ -124,12 +127,12 @@ DEV void tile_add_edge(Tile &t, const float *block, int e, int h) {
 }
 
 DEV void tile_store_edge(const Tile &t, float *block, int e, int h) {
-    float4 *p = reinterpret_cast<float4 *>(block) + e;
+    float4 *p = reinterpret_cast<float4 *>(block) + EDGE_F4(e);
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            p[(8 * bo + 2 * q + h) * 64] = make_float4(t.b[bo][4 * q + 0], t.b[bo][4 * q + 1],
+            p[(8 * bo + 2 * q + h) * 32] = make_float4(t.b[bo][4 * q + 0], t.b[bo][4 * q + 1],
                                                        t.b[bo][4 * q + 2], t.b[bo][4 * q + 3]);
 }
 

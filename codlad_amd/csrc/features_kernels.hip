@@ -220,11 +220,11 @@ __global__ __launch_bounds__(256) void features_kernel(codlad_denoiser_weights w
                 acc[4 * e + 3] = fmaf(fv, ww.w, acc[4 * e + 3]);
             }
         }
-        // chunk-major edge block (common.h, EDGE_BLOCK): [32 chunks][64 edges][4 floats]
-        float4 *out = reinterpret_cast<float4 *>(hE0 + (size_t)m * (64 * HD)) + (8 * part) * 64 + k;
+        // edge block (common.h, EDGE_BLOCK): [2 halves][32 chunks][32 edges][4 floats]
+        float4 *out = reinterpret_cast<float4 *>(hE0 + (size_t)m * (64 * HD)) + (k >> 5) * 1024 + (8 * part) * 32 + (k & 31);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            out[e * 64] = make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3]);
+            out[e * 32] = make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3]);
         if (part == 0) E_idx[(size_t)m * 64 + k] = nb[k];
     }
 }

@@ -26,9 +26,10 @@ def _require_cuda(t, what):
 
 
 def edge_rows(blocks):
-    """Edge state as the kernels keep it in HBM ([..., 32 chunks, 64 edges, 4], include/codlad_hip.h)
+    """Edge state as the kernels keep it in HBM ([..., 2 halves, 32 chunks, 32 edges, 4], include/codlad_hip.h)
     -> [..., 64 edges, 128 features]."""
-    return blocks.transpose(-3, -2).reshape(*blocks.shape[:-3], blocks.shape[-2], -1)
+    lead = blocks.shape[:-4]
+    return blocks.permute(*range(len(lead)), -4, -2, -3, -1).reshape(*lead, 64, -1)
 
 
 class Structures:
@@ -117,9 +118,9 @@ class Denoiser:
         from the uploads, bench.py)."""
         st = Structures(xyz_list, z_list, self.device)
         st.E_idx = torch.empty(st.n_snodes, KNN, dtype=torch.int32, device=self.device)
-        st.h_E0 = torch.empty(st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
+        st.h_E0 = torch.empty(st.n_snodes, 2, H // 4, KNN // 2, 4, dtype=torch.float32, device=self.device)
         if hoist_layer0:
-            st.E1 = torch.empty(2, st.n_snodes, H // 4, KNN, 4, dtype=torch.float32, device=self.device)
+            st.E1 = torch.empty(2, st.n_snodes, 2, H // 4, KNN // 2, 4, dtype=torch.float32, device=self.device)
         return st
 
     def compute_features(self, st):

@@ -142,10 +142,11 @@ typedef struct {
  * (reference models/protein_mpnn_utils.py:478-523, latent_model.py:208,216).
  * snode_info[m] = {start, L} of the structure that structure-node m belongs to.
  * Writes E_idx [n_snodes][64] (ascending distance, self first) and h_E0, one EDGE BLOCK per
- * structure node.  An edge block holds 64 edges x 128 features "chunk-major",
- * [32 chunks of 4 features][64 edges][4 floats] (feature f of edge e at 256*(f/4) + 4*e + f%4), so
- * that the 16 bytes neighbouring lanes (edges) move per instruction are neighbours in memory; slots
- * of edges e >= K are never written.  E1 and the workspace's hE use the same block layout. */
+ * structure node.  An edge block holds 64 edges x 128 features, the two halves of 32 edges one after the
+ * other and "chunk-major" within a half: [2 halves][32 chunks of 4 features][32 edges][4 floats] (feature f
+ * of edge e at float 4096*(e/32) + 128*(f/4) + 4*(e%32) + f%4), so that the 16 bytes neighbouring lanes
+ * (edges) move per instruction are neighbours in memory and a 32-edge tile is 16 contiguous KB; slots of
+ * edges e >= K are never written.  E1 and the workspace's hE use the same block layout. */
 int codlad_features_prepass(const codlad_denoiser_weights *w, const float *cg_xyz,
                             const int32_t *snode_info, int n_snodes, int max_len,
                             int32_t *E_idx, float *h_E0, void *stream);

@@ -192,17 +192,20 @@ def test_shard_units_properties():
 
 
 def test_edge_block_layout_helper():
-    """engine.edge_rows undoes the chunk-major edge-block layout documented in include/codlad_hip.h
-    (feature f of edge e at 256*(f/4) + 4*e + f%4)."""
+    """engine.edge_rows undoes the edge-block layout documented in include/codlad_hip.h
+    (feature f of edge e at 4096*(e/32) + 128*(f/4) + 4*(e%32) + f%4)."""
     from codlad_amd.engine import edge_rows
     n = 3
     rows = torch.arange(n * 64 * 128, dtype=torch.float32).view(n, 64, 128)
-    blocks = torch.empty(n, 32, 64, 4)
+    blocks = torch.empty(n, 2, 32, 32, 4)
     for f in range(128):
-        blocks[:, f // 4, :, f % 4] = rows[:, :, f]
+        for half in range(2):
+            blocks[:, half, f // 4, :, f % 4] = rows[:, 32 * half:32 * half + 32, f]
     assert torch.equal(edge_rows(blocks), rows)
     flat = blocks.view(n, -1)
-    assert float(flat[1, 256 * (77 // 4) + 4 * 13 + 77 % 4]) == float(rows[1, 13, 77])
+    for e, f in ((13, 77), (45, 6)):
+        assert float(flat[1, 4096 * (e // 32) + 128 * (f // 4) + 4 * (e % 32) + f % 4]) == float(rows[1, e, f])
+    assert tuple(edge_rows(torch.zeros(2, 5, 2, 32, 32, 4)).shape) == (2, 5, 64, 128)
 
 
 def test_split_pack_refuses_weights_outside_fp16_range():

@@ -79,6 +79,14 @@ VARIANTS = {
     # contraction and wave cost in time and in power?
     "half_lds": ([], [("common.h", "        if (g + 2 < NG) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];", "        if (g + 2 < NG && (g & 1) == 0) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];")]),
     "no_lds": ([], [("common.h", "        if (g + 2 < NG) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];", "        if (g + 2 < NG && g < 1) {\n            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];")]),
+    # the edge update's memory side alone: loads (tile, Q rows, P row) and the store stay, the three contractions and the
+    # LayerNorm go (one add keeps the Q rows live)
+    "upd_memonly": ([], [(UPD, "                gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps\n", ""),
+                         (UPD, "                tail1.run(acc, x, lane, a.gelu_a);                                    // layer 1, streamed k-steps\n", ""),
+                         (UPD, "            if (!HOISTED) tail1.start(a.W1h, lane);\n", ""),
+                         (UPD, "            gemm128_h_lds<TERMS, true>(t2, acc, w2, lane, a.gelu_a);   // layer 2 on GELU(layer 1)\n", "            for (int b = 0; b < 4; ++b) x.b[b] += acc.b[b];\n"),
+                         (UPD, "            gemm128_h_lds<TERMS, true>(x, t2, w3, lane, a.gelu_b);     // layer 3 on GELU(layer 2)\n", "            for (int b = 0; b < 4; ++b) x.b[b] += t2.b[b];\n"),
+                         (UPD, "            tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);\n", "")]),
     "msg_prio": ([], [(MSG, "    const int h = lane >> 5, c = lane & 31;\n    const NodeSpan span", "    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    const int h = lane >> 5, c = lane & 31;\n    const NodeSpan span")]),
 }
 
@@ -119,6 +127,16 @@ def run_one(name):
     w.den.forward(w.job, w.x_T, 500, check=False)      # fills the workspace the hook reads
     t = w.time_dominant_kernel()
     print(f"{name:10s} message {t['message'] * 1e3:.4f} ms   edge_update {t['edge_update'] * 1e3:.4f} ms", flush=True)
+
+
+MEMONLY = VARIANTS["upd_memonly"][1]
+VARIANTS["memonly_nostore"] = ([], MEMONLY + [(UPD, STORE, NOSTORE)])
+VARIANTS["memonly_noq"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, Pslot, h);")])
+VARIANTS["memonly_nox"] = ([], MEMONLY + [(UPD, XLOAD, "tile_load_row(x, Pslot, h);")])
+VARIANTS["memonly_noq_nostore"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, Pslot, h);"), (UPD, STORE, NOSTORE)])
+# where does the Q gather's cost come from: every lane the same row (one line per instruction) / consecutive rows
+VARIANTS["memonly_qsame"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, a.Q + (size_t)base * HD, h);")])
+VARIANTS["memonly_qseq"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, a.Q + (size_t)(base + (c < K ? c : 0)) * HD, h);")])
 
 
 if __name__ == "__main__":
