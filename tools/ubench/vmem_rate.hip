@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-enum { SAME = 0, ROWS = 1, STREAM = 2, UPD = 3 };      // UPD: 16 gathered-row loads + 16 streaming loads (+ stores in place)
+enum { SAME = 0, ROWS = 1, STREAM = 2, UPD = 3, ROWS_SKEW = 4 };   // ROWS_SKEW: the four 128-byte lines of a row rotated by the row index      // UPD: 16 gathered-row loads + 16 streaming loads (+ stores in place)
 
 template <int PATTERN, int NLOAD, bool STORE>
 __global__ __launch_bounds__(512) void k(const float4 *src, float4 *dst, const int *rows, int tiles, size_t tile_f4, float *sink) {
@@ -22,6 +22,10 @@ __global__ __launch_bounds__(512) void k(const float4 *src, float4 *dst, const i
         for (int i = 0; i < NLOAD; ++i) {
             const float4 *p;
             if (PATTERN == SAME) p = src + h + 2 * ((t + i) & 3);                 // one 128-byte line, whatever t and i
+            else if (PATTERN == ROWS_SKEW) {
+                const int r = rows[(t * 32 + c) & 4095];
+                p = src + (size_t)r * 32 + ((((i & 15) >> 2) + r) & 3) * 8 + 2 * (i & 3) + h;
+            }
             else if (PATTERN == ROWS) p = src + (size_t)rows[(t * 32 + c) & 4095] * 32 + 2 * (i & 15) + h;
             else if (PATTERN == UPD && i >= 16) p = dst + (size_t)rows[(t * 32 + c) & 4095] * 32 + 2 * (i & 15) + h;
             else p = src + tile * 1024 + (size_t)(2 * (i & 15) + h) * 32 + c;           // 16 KB per tile, 1 KB per instruction
@@ -69,6 +73,7 @@ int main() {
     run<SAME, 16, false>("16 loads, same line", src, dst, rows, n_tiles, sink);
     run<SAME, 32, false>("32 loads, same line", src, dst, rows, n_tiles, sink);
     run<ROWS, 16, false>("16 loads, 32 rows per instruction", src, dst, rows, n_tiles, sink);
+    run<ROWS_SKEW, 16, false>("16 loads, 32 rows, lines rotated", src, dst, rows, n_tiles, sink);
     run<STREAM, 16, false>("16 loads, streaming", src, dst, rows, n_tiles, sink);
     run<STREAM, 16, true>("16 loads + 16 stores, streaming", src, dst, rows, n_tiles, sink);
     run<STREAM, 32, true>("32 loads + 16 stores, streaming", src, dst, rows, n_tiles, sink);
