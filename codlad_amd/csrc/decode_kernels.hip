@@ -157,25 +157,32 @@ __global__ __launch_bounds__(128) void ic_to_xyz_kernel(const float *ca_full, co
                                                        const int32_t *orders,
                                                        const int32_t *slot_to_out, int B, int L,
                                                        int n_atoms, float *xyz_out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // the 14 atoms of the residue in LDS, one column per thread: the side-chain placements pick their three reference
+    // atoms by index (orders), and a register array indexed at run time would live in scratch memory
+    __shared__ float ax[14][128], ay[14][128], az[14][128];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + tid;
     if (t >= B * L) return;
     const int b = t / L, r = t - b * L;
     const float *ca = ca_full + ((size_t)b * (L + 2) + r) * 3;  // residue r-1 (flanking) .. r+1
     const V3 prv = v3(ca[0], ca[1], ca[2]), mid = v3(ca[3], ca[4], ca[5]), nxt = v3(ca[6], ca[7], ca[8]);
     const float *icr = ic + ((size_t)b * L + r) * 39;
-    V3 atoms[14];
-    atoms[1] = place_atom(icr + 0, mid, prv, nxt);        // N
-    atoms[2] = place_atom(icr + 3, mid, nxt, prv);        // C
-    atoms[0] = place_atom(icr + 6, atoms[2], mid, atoms[1]);  // O
-    atoms[3] = mid;                                       // CA
+    auto put = [&](int s, V3 a) { ax[s][tid] = a.x; ay[s][tid] = a.y; az[s][tid] = a.z; };
+    auto get = [&](int s) { return v3(ax[s][tid], ay[s][tid], az[s][tid]); };
+    const V3 an = place_atom(icr + 0, mid, prv, nxt);        // N
+    const V3 ac = place_atom(icr + 3, mid, nxt, prv);        // C
+    put(1, an);
+    put(2, ac);
+    put(0, place_atom(icr + 6, ac, mid, an));                // O
+    put(3, mid);                                             // CA
     for (int i = 0; i < 10; ++i) {
         const int32_t *o = orders + ((size_t)i * L + r) * 3;
-        atoms[4 + i] = place_atom(icr + 9 + 3 * i, atoms[o[2]], atoms[o[1]], atoms[o[0]]);
+        put(4 + i, place_atom(icr + 9 + 3 * i, get(o[2]), get(o[1]), get(o[0])));
     }
     float *out = xyz_out + (size_t)b * n_atoms * 3;
     for (int s = 0; s < 14; ++s) {
         const int p = slot_to_out[r * 14 + s];
-        if (p >= 0) { out[3 * p] = atoms[s].x; out[3 * p + 1] = atoms[s].y; out[3 * p + 2] = atoms[s].z; }
+        if (p >= 0) { out[3 * p] = ax[s][tid]; out[3 * p + 1] = ay[s][tid]; out[3 * p + 2] = az[s][tid]; }
     }
 }
 
