@@ -137,6 +137,9 @@ VARIANTS["memonly_noq_nostore"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(ac
 # where does the Q gather's cost come from: every lane the same row (one line per instruction) / consecutive rows
 VARIANTS["memonly_qsame"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, a.Q + (size_t)base * HD, h);")])
 VARIANTS["memonly_qseq"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, a.Q + (size_t)(base + (c < K ? c : 0)) * HD, h);")])
+# fewer k-steps of W11e resident in LDS (3 fit): what does each streamed k-step (8 fragment loads per tile and wave) cost?
+for _ks in (2, 1, 0):
+    VARIANTS[f"upd_ks{_ks}"] = ([], [("edge_args.h", "constexpr int UPD_W1_KS = 3;", f"constexpr int UPD_W1_KS = {_ks};")])
 
 
 if __name__ == "__main__":
