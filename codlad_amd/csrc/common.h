@@ -98,13 +98,21 @@ DEV void tile_store_row(const Tile &t, float *row, int h) {
 // launched back to back, no measurable difference inside the job).
 #define EDGE_BLOCK (64 * 128)
 #define EDGE_F4(e) (((e) & 31) + ((e) >> 5) * 1024)   // float4 index of edge e's first chunk; chunk stride 32
+// STREAM: the streaming (non-temporal) hint for a wave's own edge tile in the persistent kernels of large jobs - a tile
+// of the per-sample edge state is read once per launch and what is written is read next by another kernel, 1.1 GB
+// later, so neither should push the gathered Q rows and the streamed weight fragments out of the 4 MB L2s (edge
+// update -4 % in the job).  Blocks shared by the ensemble members of a structure (h_E0, E1) and the tile kernels of
+// small jobs, whose whole state stays in cache, keep the default policy.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool STREAM = false>
 DEV void tile_load_edge(Tile &t, const float *block, int e, int h) {
     const float4 *p = reinterpret_cast<const float4 *>(block) + EDGE_F4(e);
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 v = p[(8 * bo + 2 * q + h) * 32];
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p + (8 * bo + 2 * q + h) * 32);
+            const f32x4 v = STREAM ? __builtin_nontemporal_load(src) : *src;
             t.b[bo][4 * q + 0] = v.x;
             t.b[bo][4 * q + 1] = v.y;
             t.b[bo][4 * q + 2] = v.z;
@@ -126,14 +134,18 @@ DEV void tile_add_edge(Tile &t, const float *block, int e, int h) {
         }
 }
 
+template <bool STREAM = false>
 DEV void tile_store_edge(const Tile &t, float *block, int e, int h) {
     float4 *p = reinterpret_cast<float4 *>(block) + EDGE_F4(e);
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            p[(8 * bo + 2 * q + h) * 32] = make_float4(t.b[bo][4 * q + 0], t.b[bo][4 * q + 1],
-                                                       t.b[bo][4 * q + 2], t.b[bo][4 * q + 3]);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {t.b[bo][4 * q + 0], t.b[bo][4 * q + 1], t.b[bo][4 * q + 2], t.b[bo][4 * q + 3]};
+            f32x4 *dst = reinterpret_cast<f32x4 *>(p + (8 * bo + 2 * q + h) * 32);
+            if (STREAM) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
+        }
 }
 
 struct WeightQuad {

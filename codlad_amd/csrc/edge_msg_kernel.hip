@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
     Pslot[lane] = Prows[(size_t)n * 64 + lane];
     int half = 0;
     Tile x, acc, t2;
-    tile_load_edge(x, block_of(n, src), c < K ? c : 0, h);
+    tile_load_edge<!HOISTED>(x, block_of(n, src), c < K ? c : 0, h);
     tile_load_row(acc, a.Q + (size_t)(base + jA) * HD, h);
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
     float bias[4];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
             const int pn = next_half ? n : (next_node ? n2 : n), ps = next_half ? src : nsrc;
             const int pe = next_half ? (32 + c < K ? 32 + c : 0) : (c < nK ? c : 0);
             const int pq = next_half ? base + jB : nbase + njA;
-            tile_load_edge(x, block_of(pn, ps), pe, h);
+            tile_load_edge<!HOISTED>(x, block_of(pn, ps), pe, h);
             tile_load_row(acc, a.Q + (size_t)pq * HD, h);
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
             const float *c_modA = c_b2 + 2 * HD, *c_modB = c_b2 + 3 * HD;
             tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);
             tile_add_row(acc, Pslot, h);
-            tile_load_edge(x, rows, colc, h);                          // layer-1 operand and residual
+            tile_load_edge<!HOISTED>(x, rows, colc, h);                          // layer-1 operand and residual
             if (HOISTED) {
                 tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
             } else {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
             tile_scale_add_row(x, a.res_scale, c_b3, h);
             gemm128_h_lds<TERMS, true>(x, t2, w3, lane, a.gelu_b);     // layer 3 on GELU(layer 2)
             tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);
-            if (valid) tile_store_edge(x, out_rows, col, h);
+            if (valid) tile_store_edge<true>(x, out_rows, col, h);
         }
     }
 }

@@ -21,11 +21,11 @@ sys.path.insert(0, ROOT)
 # Patches on the edge-UPDATE kernel (upd_kernel_h) and, for nogelu, on both kernels.
 UPD = "edge_upd_kernel.hip"      # one hot kernel per translation unit (csrc/edge_args.h says why)
 MSG = "edge_msg_kernel.hip"
-XLOAD = "tile_load_edge(x, rows, colc, h);                          // layer-1 operand and residual"
+XLOAD = "tile_load_edge<!HOISTED>(x, rows, colc, h);                          // layer-1 operand and residual"
 QLOAD = "tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);"
-STORE = "            if (valid) tile_store_edge(x, out_rows, col, h);"
+STORE = "            if (valid) tile_store_edge<true>(x, out_rows, col, h);"
 SPAN = "    const NodeSpan span = wave_node_span(a.n_nodes, NWAVES, wave);\n"
-NOSTORE = "            if (valid && x.b[0][0] == 12345.f) tile_store_edge(x, out_rows, col, h);"
+NOSTORE = "            if (valid && x.b[0][0] == 12345.f) tile_store_edge<true>(x, out_rows, col, h);"
 # name -> (extra flags, [(file, old, new), ...])
 VARIANTS = {
     "base": ([], []),
