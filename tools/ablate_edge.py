@@ -140,6 +140,10 @@ VARIANTS["memonly_qseq"] = ([], MEMONLY + [(UPD, QLOAD, "tile_load_row(acc, a.Q 
 # fewer k-steps of W11e resident in LDS (3 fit): what does each streamed k-step (8 fragment loads per tile and wave) cost?
 for _ks in (2, 1, 0):
     VARIANTS[f"upd_ks{_ks}"] = ([], [("edge_args.h", "constexpr int UPD_W1_KS = 3;", f"constexpr int UPD_W1_KS = {_ks};")])
+# what an edge state stored pre-split (fp16 hi / lo fragments instead of fp32) could save: the lo half of the split of a
+# contraction's un-activated input removed (data stay finite; the whole split is 2.5 instructions per element, this is 1.5)
+VARIANTS["nolo_plain"] = ([], [("common.h", "    const f16x2 hh = __builtin_convertvector(x, f16x2);\n    const f16x2 ll = split_lo_pair(hh, x);",
+                                 "    const f16x2 hh = __builtin_convertvector(x, f16x2);\n    const f16x2 ll = GELU_IN ? split_lo_pair(hh, x) : f16x2{(_Float16)0, (_Float16)0};")])
 
 
 if __name__ == "__main__":
