@@ -25,6 +25,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
             wl[LDS_BLOCK_U4 + i] = g2[i];
         }
         if (tid < 32) consts[tid] = reinterpret_cast<const u32x4 *>(a.b2)[tid];
+        // b2 once more, every value four times over in each of four copies: layer 2's accumulators start as 16 registers
+        // of one value per lane (the output is transposed: lane = feature), which four 16-byte LDS reads deliver without a
+        // vector instruction (64 v_mov per tile otherwise)
+        u32x4 *rep = consts + EDGE_CONST_U4 + NWAVES * 32;
+        if (tid < 128) {
+            const unsigned bv = reinterpret_cast<const unsigned *>(a.b2)[tid];
+            for (int q = 0; q < 4; ++q) rep[q * 128 + tid] = u32x4{bv, bv, bv, bv};
+        }
     }
     __syncthreads();
     const u32x4 *w1 = wl, *w2 = wl + LDS_BLOCK_U4;
@@ -53,9 +61,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
     tile_load_edge<!HOISTED>(x, block_of(n, src), c < K ? c : 0, h);
     tile_load_row(acc, a.Q + (size_t)(base + jA) * HD, h);
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
-    float bias[4];
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo) bias[bo] = c_b2[32 * bo + c];
+    const float4 *bias_rep = reinterpret_cast<const float4 *>(consts + EDGE_CONST_U4 + NWAVES * 32) + c;
 
     // the node after this one (kept equal to the current node when there is none, so that the
     // prefetch below always has a valid address and needs no branch)
@@ -83,12 +89,18 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
             npv = Prows[(size_t)n2 * 64 + lane];
         }
         const bool next_half = first_half && K > 32;
+        {
+            int rep_off = 0;
+            asm volatile("" : "+v"(rep_off));   // or the 64 copies are read once, outside the loop, and spilled
+            const float4 *br = bias_rep + rep_off;
 #pragma unroll
-        for (int bo = 0; bo < 4; ++bo) {
-            float bv = bias[bo];
-            asm volatile("" : "+v"(bv));   // or the 64 copies are built once, outside the loop, and spilled
+            for (int bo = 0; bo < 4; ++bo)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t2.b[bo][r] = bv;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = br[q * 128 + 32 * bo];
+                    t2.b[bo][4 * q + 0] = bv.x; t2.b[bo][4 * q + 1] = bv.y;
+                    t2.b[bo][4 * q + 2] = bv.z; t2.b[bo][4 * q + 3] = bv.w;
+                }
         }
         gemm128_h_lds<TERMS, true, true>(t2, acc, w2, lane, a.gelu_a);    // layer 2 on GELU(layer 1), output transposed
         {   // edge rows and Q rows of the next tile, in flight during the epilogue
@@ -146,8 +158,8 @@ template <int TERMS>
 static void launch_msg_t(const EdgeArgs &ea, hipStream_t st) {
     static bool attr_set = false;     // one flag per TERMS instantiation
     constexpr int NW = 8;
-    const size_t lds = 16 * edge_lds_u4<false, NW>();
-    static_assert(16 * edge_lds_u4<false, NW>() <= 160 * 1024, "kernel exceeds the CU's LDS");
+    const size_t lds = 16 * (edge_lds_u4<false, NW>() + 4 * 128);     // + the replicated bias table
+    static_assert(16 * (edge_lds_u4<false, NW>() + 4 * 128) <= 160 * 1024, "kernel exceeds the CU's LDS");
     if (!attr_set) {
         set_max_lds(reinterpret_cast<const void *>(msg_kernel_h<NW, false, TERMS>), lds);
         set_max_lds(reinterpret_cast<const void *>(msg_kernel_h<NW, true, TERMS>), lds);
