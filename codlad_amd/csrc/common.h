@@ -379,7 +379,7 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, co
 // g a polynomial fit of log2(erfc(s/sqrt 2))/s on [0, 4 sqrt 2] (so neither the 1/sqrt 2 nor the 1/2
 // costs an instruction; one v_exp_f32 finishes it).  The fit minimises the error of GELU itself,
 // |x| (erfc/2) ln2 s |dg|: where erfc is tiny, g may be far off, and that is what lets a low degree
-// reach fp32 level.  Degree CODLAD_GELU_DEGREE = 5 (default; 6 and 8 selectable for A/B runs):
+// reach fp32 level.  Degree CODLAD_GELU_DEGREE = 5 (default; 4, 6 and 8 selectable for A/B runs):
 //   max |error| over |x| < 1 / 2 / 4 / 8:   deg 5  1.4e-7 / 1.6e-7 / 2.2e-7 / 3.1e-7
 //                                           deg 6  0.9e-7 / 1.2e-7 / 1.6e-7 / 2.8e-7
 //                                           deg 8  0.6e-7 / 0.9e-7 / 1.4e-7 / 2.4e-7
@@ -393,7 +393,10 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, co
 #define CODLAD_GELU_DEGREE 5
 #endif
 #define CODLAD_GELU_CLAMP 5.656854249492381f
-#if CODLAD_GELU_DEGREE == 5
+#if CODLAD_GELU_DEGREE == 4     // A/B only: one instruction per element less, max |error| 6e-7 .. 9e-7 (2-4 x degree 5)
+#define CODLAD_GELU_COEFFS {-0.0004881024651695043f, 0.007198719307780266f, -0.052146632224321365f, \
+                            -0.45959585905075073f, -1.1510004997253418f}
+#elif CODLAD_GELU_DEGREE == 5
 #define CODLAD_GELU_COEFFS {2.992418740177527e-05f, -0.0007398742018267512f, 0.007977462373673916f, \
                             -0.05323818698525429f, -0.45891568064689636f, -1.1511471271514893f}
 #elif CODLAD_GELU_DEGREE == 6
@@ -404,7 +407,7 @@ DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, co
                             -0.00028452760307118297f, 1.5291185263777152e-05f, 0.006930838339030743f,       \
                             -0.05243462696671486f, -0.4592214822769165f, -1.1511043310165405f}
 #else
-#error "CODLAD_GELU_DEGREE must be 5, 6 or 8"
+#error "CODLAD_GELU_DEGREE must be 4, 5, 6 or 8"
 #endif
 // GELU on a value that carries a power-of-two scale (block exponents of the split-fp16 modes, see
 // weights.py / DESIGN.md): for x' = 2^E x the functions below return 2^E GELU(x), bit for bit the scaled
