@@ -71,9 +71,15 @@ class Workload:
         self.cfg, self.cfg_name, self.device, self.precision = cfg, cfg_name, device, precision
         self.decode_only = cfg["decode_only"]
         strong = cfg["scaling"] == "strong"
-        self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), device, precision=precision)
-        mean, std = synth.norm_stats(cfg["dataname"], cfg["vae_type"])
-        self.dec = Decoder(synth.vqvae_state_dict(cfg["vae_type"], cfg["dataname"], VAE_SEED), device, mean, std)
+        if rank == 0 or world == 1:
+            self.den = Denoiser(synth.denoiser_state_dict(WEIGHT_SEED), device, precision=precision)
+            mean, std = synth.norm_stats(cfg["dataname"], cfg["vae_type"])
+            self.dec = Decoder(synth.vqvae_state_dict(cfg["vae_type"], cfg["dataname"], VAE_SEED), device, mean, std)
+        else:
+            # ranks > 0 hold NO weights (and, for the decoder, not even the right layout: the N6 one whatever the
+            # configuration) until rank 0's arrive by broadcast - header first, then the blob (parallel.py)
+            self.den = Denoiser(None, device, precision=precision)
+            self.dec = Decoder(None, device)
         self.tables = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T_STEPS)))
         lengths, F, E = cfg["lengths"], cfg["n_frames"], cfg["n_ensemble"]
         # weak scaling: every rank its own proteins (different seeds); strong: one job, same proteins everywhere

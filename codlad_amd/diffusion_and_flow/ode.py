@@ -93,7 +93,8 @@ def _dopri5(func, y0, ts, rtol, atol, max_steps=100000):
             n_steps += 1
             if n_steps > max_steps:
                 raise RuntimeError("dopri5: max_steps exceeded")
-            hh = min(h, t_end - t)
+            clipped = h >= t_end - t
+            hh = (t_end - t) if clipped else h
             ks = [f]
             for a, beta in zip(_DP_ALPHA, _DP_BETA):
                 ks.append(func(_tt(t + a * hh, y), combine(y, ks, beta, hh)))
@@ -102,13 +103,17 @@ def _dopri5(func, y0, ts, rtol, atol, max_steps=100000):
             tol = atol + rtol * torch.maximum(y.abs(), y1.abs())
             ratio = _rms(err / tol)
             if ratio <= 1.0:                                # accept; FSAL: k7 = f(t + h, y1)
-                t, y, f = t + hh, y1, ks[6]
+                # a clipped step lands on the output time exactly (t + (t_end - t) can be one ulp short, which would
+                # cost a further step of ~1e-16 and restart the controller from there)
+                t, y, f = (t_end if clipped else t + hh), y1, ks[6]
             # torchdiffeq _optimal_step_size: safety 0.9, ifactor 10, dfactor 0.2 (1 when the step is accepted)
             if ratio == 0.0:
                 factor = 10.0
             else:
                 factor = min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
-            h = hh * factor
+            # the controller's own step survives a clip at an output time: an ACCEPTED clipped step says nothing
+            # against h (only that hh <= h was fine too), so the next interval starts from h, not from the remainder
+            h = max(h, hh * factor) if (clipped and ratio <= 1.0) else hh * factor
         out.append(y)
     return torch.stack(out)
 

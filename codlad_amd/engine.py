@@ -103,13 +103,20 @@ class Job:
 class Denoiser:
     """mpnn_diffusion on the GPU."""
 
-    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION, block_exponents=True):
+    def __init__(self, state_dict, device, precision=DEFAULT_PRECISION, block_exponents=True, self_condition=False,
+                 out_dim=6):
+        """state_dict None: the layout of a model with the given flags and NO weights - what a rank that loads no
+        checkpoint starts from; `parallel.broadcast_weights(den.weights)` then fills it with rank 0's."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")
         self.lib = _lib.lib()
-        self.weights = DenoiserWeights(state_dict, self.device, precision, block_exponents=block_exponents)
+        if state_dict is None:
+            self.weights = DenoiserWeights.empty(self.device, self_condition, out_dim, precision)
+        else:
+            self.weights = DenoiserWeights(state_dict, self.device, precision, block_exponents=block_exponents)
         self._mods_cache = {}
+        self._mods_generation = self.weights.generation
 
     # -- step-invariant part -------------------------------------------------------------------
     def new_structures(self, xyz_list, z_list, hoist_layer0=True):
@@ -143,10 +150,11 @@ class Denoiser:
     def features_tag(self):
         """What the hoisted layer-0 terms E1 depend on besides the structure: in the split-fp16 modes they carry
         encoder layer 0's block exponents (E1[0] = 2^e1 W1e h_E0, E1[1] = 2^e11 W11e h_E0), in the fp32 mode none."""
+        # generation: h_E0 and E1 are functions of the weights too, so a broadcast (rebind) makes them stale
         if self.weights.precision == "f32":
-            return ("f32",)
+            return ("f32", self.weights.generation)
         ex = self.weights.exponents["enc0"]
-        return ("split", self.weights.precision, ex["e1"], ex["e11"])
+        return ("split", self.weights.precision, ex["e1"], ex["e11"], self.weights.generation)
 
     def _fresh_features(self, st):
         if st.features_tag != self.features_tag():     # e.g. set_precision() after the structures were prepared
@@ -164,6 +172,9 @@ class Denoiser:
         non-integer value switches the whole list to the float entry point)."""
         fractional = any(float(t) != int(t) for t in t_values)
         key = tuple(float(t) for t in t_values) if fractional else tuple(int(t) for t in t_values)
+        if self._mods_generation != self.weights.generation:      # the weights changed under the cache (broadcast)
+            self._mods_cache.clear()
+            self._mods_generation = self.weights.generation
         if refresh or key not in self._mods_cache:
             mods = torch.empty(len(key), MODS, dtype=torch.float32, device=self.device)
             if fractional:
@@ -264,16 +275,28 @@ class Denoiser:
 class Decoder:
     """De-normalise + VQ lookup + IC decoder + ic_to_xyz."""
 
-    def __init__(self, state_dict, device, mean3=None, std3=None):
+    def __init__(self, state_dict, device, mean3=None, std3=None, angle=False, n_codes=4096):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("codlad_amd runs on an MI355X only; no CPU path exists")
         self.lib = _lib.lib()
-        self.weights = DecoderWeights(state_dict, self.device)
+        # state_dict None: a rank that loads no checkpoint (`angle` / `n_codes` give the layout; a broadcast whose
+        # header says otherwise re-derives it)
+        if state_dict is None:
+            self.weights = DecoderWeights.empty(self.device, angle, n_codes)
+        else:
+            self.weights = DecoderWeights(state_dict, self.device, mean3, std3)
         f = dict(dtype=torch.float32, device=self.device)
-        self.mean = (torch.zeros(3) if mean3 is None else mean3).to(**f).contiguous()
-        self.std = (torch.ones(3) if std3 is None else std3).to(**f).contiguous()
         self._unit = (torch.zeros(3, **f), torch.ones(3, **f))
+
+    # the de-normalisation statistics live in the weight blob (they travel with a broadcast)
+    @property
+    def mean(self):
+        return self.weights.mean
+
+    @property
+    def std(self):
+        return self.weights.std
 
     def vq(self, x, normalised=True):
         """x [..., 3] -> (idx int64 [n], z_q [..., 3], latent [..., 3]); de-normalises first when

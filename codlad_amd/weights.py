@@ -103,14 +103,26 @@ def block_exponent(*mats):
     return int(max(-MAX_CHAIN_EXP, min(MAX_CHAIN_EXP, min(want, limit))))
 
 
-def _chain(*es):
+BIAS_HEADROOM_LOG2 = 12     # 2^E max|bias| <= 2^12 at a GELU input: a factor 16 below the fp16 maximum for the W x part
+
+
+def _chain(*es, biases=()):
     """Clamp exponents along an MLP so that the accumulated sums that reach a GELU (after the first and the second
     layer) stay within +-MAX_CHAIN_EXP; a third layer's sum only scales a residual and a LayerNorm epsilon
-    (2^(2E) must be a normal fp32): +-40."""
+    (2^(2E) must be a normal fp32): +-40.
+    biases[i] (optional): everything ADDED to layer i's pre-activation besides W x (the bias, the decoder's W1s W_s
+    table).  Those are stored pre-multiplied by the accumulated 2^E and ride on the GELU output that is then split
+    into fp16 halves, so E is also capped by their magnitude: a layer of tiny weights and ordinary biases (b ~ 1
+    with E = 16 would be 65536) must not be lifted out of the fp16 range by its own exponent."""
     out, acc = [], 0
     for i, e in enumerate(es):
         lim = MAX_CHAIN_EXP if i < 2 else 40
-        e = max(-lim - acc, min(lim - acc, e))
+        hi = lim - acc
+        if i < 2 and i < len(biases) and biases[i] is not None:
+            mx = float(torch.as_tensor(biases[i]).detach().abs().max())
+            if mx > 0.0 and math.isfinite(mx):
+                hi = min(hi, BIAS_HEADROOM_LOG2 - math.ceil(math.log2(mx)) - acc)
+        e = max(-lim - acc, min(hi, e))
         out.append(e)
         acc += e
     return out
@@ -224,9 +236,10 @@ def denoiser_tensors_h(sd, strict=True, use_exponents=True):
                 Z = torch.zeros(H, H)
                 W1, W11, Win, Wout = Z.repeat(1, 3), Z.repeat(1, 3), Z.repeat(4, 1), Z.repeat(1, 4)
                 W2 = W3 = W12 = W13 = Z
-            e1, e2 = _chain(expo(W1), expo(W2))
-            e11, e12, e13 = _chain(expo(W11), expo(W12), expo(W13))
-            e_in, e_out = _chain(expo(Win), expo(Wout))
+            bias = (lambda k: None) if zero else (lambda k: g(f"{p}.{k}.bias"))
+            e1, e2 = _chain(expo(W1), expo(W2), biases=(bias("W1"), bias("W2")))
+            e11, e12, e13 = _chain(expo(W11), expo(W12), expo(W13), biases=(bias("W11"), bias("W12")))
+            e_in, e_out = _chain(expo(Win), expo(Wout), biases=(bias("dense.W_in"),))
             e3 = expo(W3)                      # node kernel: taken out by a constant multiply, never reaches a GELU
             exps[f"enc{l}"] = dict(e1=e1, e2=e2, e3=e3, e11=e11, e12=e12, e13=e13, e_in=e_in, e_out=e_out)
             t[e_ + "W1e"] = pk(W1[:, 128:256], e1); t[e_ + "W2"] = pk(W2, e2); t[e_ + "W3"] = pk(W3, e3)
@@ -254,8 +267,11 @@ def denoiser_tensors_h(sd, strict=True, use_exponents=True):
                 Z = torch.zeros(H, H)
                 W1, Win, Wout, W2, W3 = Z.repeat(1, 4), Z.repeat(4, 1), Z.repeat(1, 4), Z, Z
             # h_ESV = [h_E|h_S_j|h_V_j] + [h_E|h_S_j|h_Venc_j] (latent_model.py:260-261): h_E and h_S doubled
-            e1, e2 = _chain(expo(W1[:, 0:128], 2.0 * W1[:, 128:256], W1[:, 384:512]), expo(W2))
-            e_in, e_out = _chain(expo(Win), expo(Wout))
+            bias = (lambda k: None) if zero else (lambda k: g(f"{p}.{k}.bias"))
+            b1_all = None if zero else torch.cat([g(f"{p}.W1.bias"), F.linear(2.0 * Ws, W1[:, 256:384]).reshape(-1)])
+            e1, e2 = _chain(expo(W1[:, 0:128], 2.0 * W1[:, 128:256], W1[:, 384:512]), expo(W2),
+                            biases=(b1_all, bias("W2")))
+            e_in, e_out = _chain(expo(Win), expo(Wout), biases=(bias("dense.W_in"),))
             e3 = expo(W3)
             exps[f"dec{l}"] = dict(e1=e1, e2=e2, e3=e3, e_in=e_in, e_out=e_out)
             t[d_ + "W1e"] = pk(W1[:, 128:256], e1, 2.0)
@@ -337,12 +353,102 @@ class Blob:
 PRECISIONS = {"f32": 0, "f16x4": 1, "f16x3": 2}      # include/codlad_hip.h, codlad_denoiser_weights.precision
 DEFAULT_PRECISION = "f16x3"
 
+# Blob header.  The first META_FLOATS floats of every blob hold, as exactly representable integers, everything the
+# kernels need that is NOT a pointer: contraction mode, model flags and the block exponents of the split-fp16
+# copies (they scale biases, GELU constants, the residual and the LayerNorm epsilon: a rank that received another
+# rank's blocks but kept its own exponents would be silently wrong by powers of two).  `parallel.broadcast_weights`
+# sends the header first, a receiving rank re-derives the layout from it (it may have started from any weights, or
+# from none: `DenoiserWeights.empty`), then the blob travels as one buffer and `rebind()` reads the header back.
+META_FLOATS = 64
+META_MAGIC = 0xC0D1AD            # < 2^24: exact in fp32
+META_LAYOUT_VERSION = 3
+KIND_DENOISER, KIND_DECODER = 1, 2
+ENC_EXP_NAMES = ("e1", "e2", "e3", "e11", "e12", "e13", "e_in", "e_out")
+DEC_EXP_NAMES = ("e1", "e2", "e3", "e_in", "e_out")
+
+
+def _check_header(hdr, kind):
+    h = [int(round(float(v))) for v in hdr.reshape(-1)[:META_FLOATS].tolist()]
+    if h[0] != META_MAGIC or h[1] != kind or h[2] != META_LAYOUT_VERSION:
+        raise RuntimeError(f"weight blob header mismatch: magic {h[0]:#x} kind {h[1]} layout {h[2]} "
+                           f"(expected {META_MAGIC:#x} / {kind} / {META_LAYOUT_VERSION})")
+    return h
+
+
+def denoiser_shapes(self_condition=False, out_dim=6):
+    """name -> shape of the 108 checkpoint tensors of `mpnn_diffusion` (reference models/latent_model.py:119-148)."""
+    sh = OrderedDict()
+
+    def lin(name, o, i, bias=True):
+        sh[name + ".weight"] = (o, i)
+        if bias:
+            sh[name + ".bias"] = (o,)
+
+    lin("t_embedder.mlp.0", H, 256); lin("t_embedder.mlp.2", H, H)
+    lin("x_in", H, 6 if self_condition else 3)
+    lin("features.embeddings.linear", 16, 66)
+    lin("features.edge_embedding", H, 167, bias=False)
+    sh["features.norm_edges.weight"], sh["features.norm_edges.bias"] = (H,), (H,)
+    lin("W_e", H, H)
+    sh["W_s.weight"] = (30, H)
+    for l in range(3):
+        p = f"encoder_layers.{l}."
+        for n, i in (("W1", 3 * H), ("W2", H), ("W3", H), ("W11", 3 * H), ("W12", H), ("W13", H)):
+            lin(p + n, H, i)
+        lin(p + "dense.W_in", 4 * H, H); lin(p + "dense.W_out", H, 4 * H)
+        lin(p + "adaLN_modulation.1", 9 * H, H)
+    for l in range(3):
+        p = f"decoder_layers.{l}."
+        for n, i in (("W1", 4 * H), ("W2", H), ("W3", H)):
+            lin(p + n, H, i)
+        lin(p + "dense.W_in", 4 * H, H); lin(p + "dense.W_out", H, 4 * H)
+        lin(p + "adaLN_modulation.1", 6 * H, H)
+    lin("W_out.linear", out_dim, H)
+    lin("W_out.adaLN_modulation.1", 2 * H, H)
+    return sh
+
+
+def decoder_shapes(angle=False, n_codes=4096):
+    """name -> shape of the decoder-side VQ-VAE tensors `decoder_tensors` reads (reference models/vae_model.py:318-373,
+    414-465, 704-706; codebook in the vector_quantize_pytorch layout).  n_codes = 0: no codebook."""
+    sh = OrderedDict()
+    F = 40
+    Ft = F + 10 if angle else F
+    p = "equivaraintconv."
+
+    def lin(name, o, i):
+        sh[name + ".weight"], sh[name + ".bias"] = (o, i), (o,)
+
+    lin("map_out", 36, 3)
+    sh[p + "res_embed.weight"] = (25, 4)
+    for i in range(4):
+        lin(f"{p}message_blocks.{i}.inv_dense.0", F, F); lin(f"{p}message_blocks.{i}.inv_dense.1", F, F)
+        lin(f"{p}message_blocks.{i}.dist_embed.block.1", F, 15)
+        lin(f"{p}dense_blocks.{i}.1", F, F); lin(f"{p}dense_blocks.{i}.3", F, F)
+        lin(f"{p}sidechain_torsion_blocks.{i}.1", Ft, Ft); lin(f"{p}sidechain_torsion_blocks.{i}.3", Ft, Ft)
+    sh[p + "backbone_dist.weight"], sh[p + "sidechain_dist.weight"] = (25, 3), (25, 10)
+    lin(p + "backbone_angle.1", 3, F); lin(p + "backbone_angle.3", 3, 3)
+    lin(p + "backbone_torsion.1", 3, F + 3); lin(p + "backbone_torsion.3", 3, 3)
+    lin(p + "final_torsion.1", 10, Ft); lin(p + "final_torsion.3", 10, 10)
+    if angle:
+        lin(p + "sidechain_angle.1", 10, F); lin(p + "sidechain_angle.3", 10, 10)
+    else:
+        sh[p + "sidechain_angle.weight"] = (25, 10)
+    if n_codes:
+        sh["quantize._codebook.embed"] = (1, n_codes, 3)
+    return sh
+
+
+def _zeros(shapes):
+    return OrderedDict((k, torch.zeros(*v)) for k, v in shapes.items())
+
 
 class DenoiserWeights:
     def __init__(self, state_dict, device, precision=DEFAULT_PRECISION, block_exponents=True):
         if precision not in PRECISIONS:
             raise ValueError(f"precision {precision!r}: one of {sorted(PRECISIONS)}")
-        tensors = denoiser_tensors(state_dict)
+        tensors = OrderedDict(meta=torch.zeros(META_FLOATS))
+        tensors.update(denoiser_tensors(state_dict))
         split, self.exponents, n_bad = denoiser_tensors_h(state_dict, strict=precision != "f32",
                                                           use_exponents=block_exponents)
         self.splittable = n_bad == 0      # False: some layer has no fp16 split, fp32-MFMA mode only
@@ -351,7 +457,55 @@ class DenoiserWeights:
         self.precision = precision
         self.self_condition = tensors["x_in_w"].shape[1] == 6
         self.out_dim = int(tensors["out_w"].shape[0])
+        self.generation = 0               # bumped whenever the blob's content or the host-side fields change
+        self.sync_meta()
         self.struct = self._fill()
+
+    @classmethod
+    def empty(cls, device, self_condition=False, out_dim=6, precision=DEFAULT_PRECISION):
+        """The layout of a model with these flags, every weight zero: what a rank that loads no checkpoint
+        starts from before `parallel.broadcast_weights` fills it with rank 0's."""
+        return cls(_zeros(denoiser_shapes(self_condition, out_dim)), device, precision)
+
+    # -- header ------------------------------------------------------------------------------------
+    def header(self):
+        """[META_FLOATS] host fp32 tensor: magic, kind, layout version, precision, self_condition, out_dim,
+        splittable, blob size, then the 3 x 8 encoder and 3 x 5 decoder block exponents."""
+        h = [META_MAGIC, KIND_DENOISER, META_LAYOUT_VERSION, PRECISIONS[self.precision], int(self.self_condition),
+             self.out_dim, int(self.splittable), self.blob.data.numel()]
+        for l in range(3):
+            h += [self.exponents[f"enc{l}"][n] for n in ENC_EXP_NAMES]
+        for l in range(3):
+            h += [self.exponents[f"dec{l}"][n] for n in DEC_EXP_NAMES]
+        assert len(h) <= META_FLOATS and h[7] < 2 ** 24
+        return torch.tensor(h + [0] * (META_FLOATS - len(h)), dtype=torch.float32)
+
+    def sync_meta(self):
+        """Host fields -> the header inside the blob (what travels with a broadcast)."""
+        self.blob.view("meta").copy_(self.header())
+
+    def adopt_header(self, hdr):
+        """Take over another rank's header BEFORE its blob arrives: re-derive the layout when the model flags
+        differ (x_in / W_out have other shapes then) and set every host-side field from it."""
+        h = _check_header(hdr, KIND_DENOISER)
+        sc, od = bool(h[4]), h[5]
+        if (sc, od) != (self.self_condition, self.out_dim):
+            fresh = DenoiserWeights.empty(self.blob.data.device, sc, od, self.precision)
+            self.blob, self.self_condition, self.out_dim = fresh.blob, sc, od
+        if h[7] != self.blob.data.numel():
+            raise RuntimeError(f"weight blob of {h[7]} floats announced, local layout has {self.blob.data.numel()}")
+        self._take_fields(h)
+
+    def _take_fields(self, h):
+        self.precision = {v: k for k, v in PRECISIONS.items()}[h[3]]
+        self.splittable = bool(h[6])
+        o = 8
+        for l in range(3):
+            self.exponents[f"enc{l}"] = dict(zip(ENC_EXP_NAMES, h[o:o + 8]))
+            o += 8
+        for l in range(3):
+            self.exponents[f"dec{l}"] = dict(zip(DEC_EXP_NAMES, h[o:o + 5]))
+            o += 5
 
     def _fill(self):
         w = _lib.DenoiserWeights()
@@ -394,17 +548,59 @@ class DenoiserWeights:
             raise ValueError("these weights hold a block outside the fp16 range: only precision 'f32' can run them")
         self.precision = precision
         self.struct.precision = PRECISIONS[precision]
+        self.sync_meta()
+        self.generation += 1
 
     def rebind(self):
-        """Re-derive the pointers after the blob storage changed (e.g. after a broadcast)."""
+        """After the blob's content or storage changed (a broadcast): read the header back from the blob - the
+        block exponents, the contraction mode and the model flags are whatever the blob says, never what this rank
+        derived from its own weights - and re-derive the pointers."""
+        h = _check_header(self.blob.view("meta").cpu(), KIND_DENOISER)
+        if (bool(h[4]), h[5]) != (self.self_condition, self.out_dim) or h[7] != self.blob.data.numel():
+            raise RuntimeError("blob header does not match this layout: adopt_header() must precede the blob")
+        self._take_fields(h)
+        self.generation += 1
         self.struct = self._fill()
+
+    def checksum(self):
+        """64-bit sum of the blob's 32-bit words (ranks compare it after a broadcast)."""
+        return int(self.blob.data.view(torch.int32).to(torch.int64).sum())
 
 
 class DecoderWeights:
-    def __init__(self, state_dict, device):
-        tensors, self.angle = decoder_tensors(state_dict)
+    def __init__(self, state_dict, device, mean3=None, std3=None):
+        tensors = OrderedDict(meta=torch.zeros(META_FLOATS))
+        # de-normalisation statistics of the latent (reference utils/dataset_module.py:230-256): part of the blob so
+        # that they travel with the codebook (SURVEY.md 8e: "packed weight blob + codebook + norm stats from rank 0")
+        tensors["norm_mean"] = (torch.zeros(3) if mean3 is None else mean3).detach().float().cpu().reshape(3).clone()
+        tensors["norm_std"] = (torch.ones(3) if std3 is None else std3).detach().float().cpu().reshape(3).clone()
+        dec, self.angle = decoder_tensors(state_dict)
+        tensors.update(dec)
+        self.n_codes = int(tensors["codebook"].shape[0]) if "codebook" in tensors else 0
         self.blob = Blob(tensors, device)
+        self.generation = 0
+        self.sync_meta()
         self.struct = self._fill()
+
+    @classmethod
+    def empty(cls, device, angle=False, n_codes=4096):
+        return cls(_zeros(decoder_shapes(angle, n_codes)), device)
+
+    def header(self):
+        h = [META_MAGIC, KIND_DECODER, META_LAYOUT_VERSION, int(self.angle), self.n_codes, self.blob.data.numel()]
+        return torch.tensor(h + [0] * (META_FLOATS - len(h)), dtype=torch.float32)
+
+    def sync_meta(self):
+        self.blob.view("meta").copy_(self.header())
+
+    def adopt_header(self, hdr):
+        h = _check_header(hdr, KIND_DECODER)
+        angle, n_codes = bool(h[3]), h[4]
+        if (angle, n_codes) != (self.angle, self.n_codes):
+            fresh = DecoderWeights.empty(self.blob.data.device, angle, n_codes)
+            self.blob, self.angle, self.n_codes = fresh.blob, angle, n_codes
+        if h[5] != self.blob.data.numel():
+            raise RuntimeError(f"decoder blob of {h[5]} floats announced, local layout has {self.blob.data.numel()}")
 
     def _fill(self):
         w = _lib.DecoderWeights()
@@ -422,8 +618,23 @@ class DecoderWeights:
         return w
 
     def rebind(self):
+        h = _check_header(self.blob.view("meta").cpu(), KIND_DECODER)
+        if (bool(h[3]), h[4]) != (self.angle, self.n_codes) or h[5] != self.blob.data.numel():
+            raise RuntimeError("blob header does not match this layout: adopt_header() must precede the blob")
+        self.generation += 1
         self.struct = self._fill()
+
+    def checksum(self):
+        return int(self.blob.data.view(torch.int32).to(torch.int64).sum())
 
     @property
     def codebook(self):
         return self.blob.view("codebook")
+
+    @property
+    def mean(self):
+        return self.blob.view("norm_mean")
+
+    @property
+    def std(self):
+        return self.blob.view("norm_std")

@@ -64,7 +64,8 @@ def odeint_dopri5(func, y0, ts, rtol, atol):
     out, n_eval = [y0], 2
     for t_end in ts[1:]:
         while t < t_end:
-            hh = min(h, t_end - t)
+            clipped = h >= t_end - t
+            hh = (t_end - t) if clipped else h
             ks = [f]
             for a, beta in zip(_tables._DP_ALPHA, _tables._DP_BETA):
                 ks.append(func(t + a * hh, _combine(y, ks, beta, hh)))
@@ -73,8 +74,8 @@ def odeint_dopri5(func, y0, ts, rtol, atol):
             err = _combine(torch.zeros_like(y), ks, _tables._DP_C_ERR, hh)
             ratio = rms(err / (atol + rtol * torch.maximum(y.abs(), y1.abs())))
             if ratio <= 1.0:
-                t, y, f = t + hh, y1, ks[6]
+                t, y, f = (t_end if clipped else t + hh), y1, ks[6]
             factor = 10.0 if ratio == 0.0 else min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
-            h = hh * factor
+            h = max(h, hh * factor) if (clipped and ratio <= 1.0) else hh * factor
         out.append(y)
     return torch.stack(out), n_eval

@@ -36,8 +36,12 @@ def build_model(args):
                                       diffusion=args.model, self_condition=args.self_condition)
 
 
-def load_denoiser(args, device):
+def load_denoiser(args, device, load=True):
+    """load=False (ranks > 0 of a multi-GPU run): the module with its constructor's initialisation and NO file
+    access - rank 0's weights arrive by broadcast (`parallel.broadcast_module_state`)."""
     model = build_model(args)
+    if not load:
+        return model.to(device).eval()
     if args.synthetic_weights:
         model.load_state_dict(synth.denoiser_state_dict(1234, self_condition=args.self_condition,
                                                         flow=args.model != "diffusion"), strict=True)
@@ -52,7 +56,9 @@ def load_denoiser(args, device):
     return model.to(device).eval()
 
 
-def load_vae(args, device):
+def load_vae(args, device, load=True):
+    if not load:
+        return build_vae(args.vae_type).to(device).eval()
     if args.synthetic_weights:
         vae = build_vae(args.vae_type)
         load_decoder_state(vae, synth.vqvae_state_dict(args.vae_type, args.data_type, 4321))
@@ -147,6 +153,14 @@ class Evaluation:
         return stats
 
 
+def unit_generator(args, batch_id, device):
+    """The noise source of one batch (a data file's <= 96 frames x num_ensemble members): seeded by the run's seed
+    and the batch's position in the data set alone, so a structure is sampled from the same numbers on 1 or 8 GPUs."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(args.seed + args.sample_index + batch_id)
+    return gen
+
+
 def run_sampling(model, args, x, mask=None, batch=None):
     """Flow-matching sampling, reference test.py:214-250: integrate dx/dt = model(x, t) from t = 0 (noise) to 1 over
     t_span = linspace(0, 1, --steps) with --method / --atol / --rtol; torchdiffeq.odeint is replaced by
@@ -176,14 +190,19 @@ def main(args):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.set_grad_enabled(False)
-    torch.manual_seed(args.seed + args.sample_index + 1000 * rank)
+    # the global streams are seeded like the reference's (test.py:256) but NOT used for the latents: every batch
+    # draws its noise from its own generator (unit_generator), so the numbers a structure gets do not depend on the
+    # world size or on which rank the batch was dealt to
+    torch.manual_seed(args.seed + args.sample_index)
     np.random.seed(args.seed + args.sample_index)
     if args.cfg_scale > 1.0:
         raise NotImplementedError("cfg_scale > 1 calls model.forward_with_cfg, which the reference model "
                                   "does not define (dead path)")
-    vae = load_vae(args, device)
+    # only rank 0 reads checkpoints; the other ranks receive its weights (reference: one process, test.py:264-286)
+    vae = load_vae(args, device, load=rank == 0)
+    model = None
     if args.experiment == "latent":
-        model = load_denoiser(args, device)
+        model = load_denoiser(args, device, load=rank == 0)
         diffusion = None if args.model != "diffusion" else create_diffusion(str(args.num_sampling_steps), noise_schedule=args.noise_schedule,
                                      predict_xstart=args.predict_xstart,
                                      rescale_learned_sigmas=args.rescale_learned_sigmas,
@@ -191,15 +210,24 @@ def main(args):
                                      self_condition=hasattr(model, "self_condition") and args.self_condition)
     elif args.experiment != "recon":
         raise NotImplementedError(f"experiment {args.experiment!r}: latent and recon are built")
+    if world > 1:
+        from codlad_amd import parallel
+        mods = [m for m in (model, vae) if m is not None]
+        parallel.broadcast_module_state(*mods, src=0)
+        # every rank packs the same parameters into its device blobs; prove it (and leave a record of the rank
+        # count and backend the collective ran on)
+        sums = [m.engine().weights.checksum() for m in mods]
+        parallel.verify_checksums(sums, what="weights broadcast from rank 0")
     save_dir = f"./logs/generated_samples_{args.sample_index}_{args.model_step}/{args.exp}_{args.data_type}"
     os.makedirs(save_dir, exist_ok=True)
     total, t_all = 0, time.time()
-    units = list(iter_batches(args))
+    units = [(g,) + u for g, u in enumerate(iter_batches(args))]      # g: the batch's id, the same on every world size
     if world > 1:
         from codlad_amd.parallel import shard_units, unit_cost
-        costs = [int(b["num_CGs"].shape[0]) * unit_cost(int(b["num_CGs"][0])) for _n, b, _i in units]
+        costs = [int(b["num_CGs"].shape[0]) * unit_cost(int(b["num_CGs"][0])) for _g, _n, b, _i in units]
         units = [units[u] for u in shard_units(costs, world)[rank]]
-    for name, batch, info in units:
+    for g, name, batch, info in units:
+        gen = unit_generator(args, g, device)
         batch = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in batch.items()}
         B = int(batch["num_CGs"].shape[0])
         L = int(batch["num_CGs"][0])
@@ -209,10 +237,11 @@ def main(args):
         # E ensemble members of every frame = the batch repeated E times along the sample axis
         rep = {k: v for k, v in batch.items()}
         if args.experiment == "latent":
-            z = torch.randn(B * E, L, args.latent_size, device=device)
+            z = torch.randn(B * E, L, args.latent_size, device=device, generator=gen)
             if args.model == "diffusion":
                 samples = diffusion.p_sample_loop(model.forward, z.shape, z, clip_denoised=False,
-                                                  model_kwargs=dict(y=None, mask=mask, batch=rep), device=device)
+                                                  model_kwargs=dict(y=None, mask=mask, batch=rep), device=device,
+                                                  step_noise=diffusion._draw_noise(z, generator=gen))
             else:                                               # --model fm / icfm / otcfm ...: ODE sampling
                 samples = run_sampling(model, args, z, mask=mask, batch=rep)
             samples = get_norm_feature(samples, args.vae_type, norm_channel=args.norm, norm_single=args.norm_single,
@@ -220,7 +249,7 @@ def main(args):
         else:
             mean = torch.tensor(synth.NORM_STATS[(args.data_type, args.vae_type)][0], device=device)
             std = torch.tensor(synth.NORM_STATS[(args.data_type, args.vae_type)][1], device=device)
-            samples = torch.randn(B * E, L, args.latent_size, device=device) * std + mean   # stands in for the encoder
+            samples = torch.randn(B * E, L, args.latent_size, device=device, generator=gen) * std + mean   # stands in for the encoder
         nres = L + 2
         og = batch["OG_CG_nxyz"].reshape(-1, nres, 4)
         xyz_all = []

@@ -55,7 +55,7 @@ E2E_CASES = {
 # full denoiser forward of the reference on the L46_B2 inputs (tools/gen_golden.py g10).
 ENVELOPE_GEOMETRY = (46, 2, 12)
 ENVELOPE_CASES = ("xavier", "blocks_1e-2", "blocks_1e-3", "small_first_1e-2", "small_first_1e-3", "large_first_1e2",
-                  "norm_edges_x30", "adaln_x8")
+                  "norm_edges_x30", "adaln_x8", "tiny_first_big_bias")
 _BLOCK_TAGS = (".W1.", ".W2.", ".W3.", ".W11.", ".W12.", ".W13.", ".dense.W_in.", ".dense.W_out.")
 
 
@@ -67,6 +67,9 @@ def envelope_state_dict(name):
       small_first_<s> the FIRST layer of every MLP (W1, W11, dense.W_in; weight and bias) scaled by s and the second
                       (W2, W12, dense.W_out weight) by 1/s: small weights that still carry the signal - the case a
                       trained net with one small layer looks like; large_first_1e2: the other way round;
+      tiny_first_big_bias  the first-layer WEIGHTS x 1e-5 and their BIASES x 10 (|b| up to ~4): the matrix alone asks
+                      for the largest block exponent (16), which would carry the pre-multiplied bias to 2^16 x 4, beyond
+                      the fp16 range of the activations - the exponent has to be capped by the bias (weights._chain);
       norm_edges_x30  features.norm_edges.weight x 30: edge features of magnitude ~30 enter the first contraction;
       adaln_x8        every adaLN head x 8: large scale / shift / gate vectors."""
     if name == "xavier":
@@ -84,6 +87,10 @@ def envelope_state_dict(name):
                 sd[k] = sd[k] * s
             elif k.endswith(".weight") and any(t in k for t in (".W2.", ".W12.", ".dense.W_out.")):
                 sd[k] = sd[k] / s
+    elif name == "tiny_first_big_bias":
+        for k in sd:
+            if any(t in k for t in (".W1.", ".W11.", ".dense.W_in.")):
+                sd[k] = sd[k] * (1e-5 if k.endswith(".weight") else 10.0)
     elif name == "norm_edges_x30":
         sd["features.norm_edges.weight"] = sd["features.norm_edges.weight"] * 30.0
     elif name == "adaln_x8":

@@ -17,11 +17,17 @@ WEIGHT_SEED, VAE_SEED = 1234, 4321
 
 class Config:
     def __init__(self, name, lengths, n_frames, n_ensemble, vae_type, dataname, T=100, seed0=1000, device="cuda:0",
-                 weight_seed=WEIGHT_SEED, vae_seed=VAE_SEED):
+                 weight_seed=WEIGHT_SEED, vae_seed=VAE_SEED, denoiser_sd=None, no_weights=False):
+        """denoiser_sd: a state dict instead of the seeded one; no_weights: both engines start EMPTY (a rank that
+        waits for rank 0's broadcast), the decoder even with the N6 layout whatever `vae_type` says."""
         self.name, self.T, self.device = name, T, torch.device(device)
-        self.den = Denoiser(synth.denoiser_state_dict(weight_seed), self.device)
-        mean, std = synth.norm_stats(dataname, vae_type)
-        self.dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, vae_seed), self.device, mean, std)
+        if no_weights:
+            self.den, self.dec = Denoiser(None, self.device), Decoder(None, self.device)
+        else:
+            self.den = Denoiser(denoiser_sd if denoiser_sd is not None else synth.denoiser_state_dict(weight_seed),
+                                self.device)
+            mean, std = synth.norm_stats(dataname, vae_type)
+            self.dec = Decoder(synth.vqvae_state_dict(vae_type, dataname, vae_seed), self.device, mean, std)
         self.tables = Tables(named_betas("linear", 1000), space_timesteps(1000, str(T)))
         self.proteins = [synth.make_protein(L, seed0 + i, n_frames=n_frames) for i, L in enumerate(lengths)]
         # unit id -> (protein, frame, member); ids are stable across shardings

@@ -32,21 +32,27 @@ def _env():
     return env
 
 
-@pytest.mark.timeout(600)
-def test_two_rank_job_equals_single_process(tmp_path):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["r1_envelope", "r0_envelope", "r1_empty"])
+def test_two_rank_job_equals_single_process(tmp_path, mode):
+    """Rank 1 starts from weights with OTHER block exponents (or from none, with a decoder blob of the wrong layout):
+    after the broadcast the exponents in every rank's kernel struct are rank 0's and the gathered coordinates equal
+    the single-process result bit for bit."""
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), "2",
-                               str(port), str(tmp_path)], env=_env(), cwd=ROOT,
+                               str(port), str(tmp_path), mode], env=_env(), cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=500)[0] for p in procs]
+    outs = [p.communicate(timeout=800)[0] for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    assert "ranks=2 backend=gloo" in outs[0] and "equal on every rank" in outs[0]
     got = np.load(os.path.join(tmp_path, "gathered.npz"))
     assert got["shard_sizes"].tolist() == [6, 6]
     # single process, rank 0's weights, all 12 units in one job
     from tests import multirank_worker as mw
-    from tests import pipeline
-    cfg = pipeline.Config("mr", mw.LENGTHS, mw.N_FRAMES, mw.N_ENSEMBLE, "N6", "PED", T=mw.T)
+    cfg = mw.job_config(mode, 0)
+    assert np.array_equal(got["exponents"], np.array(mw.exponent_table(cfg.den.weights)))
+    assert bool(np.abs(got["exponents"]).sum()) == (mode == "r0_envelope")
     whole = cfg.run_units(list(range(len(cfg.units))))
     assert len(cfg.units) == 12
     for u in range(12):
@@ -115,6 +121,14 @@ def test_cli_single_rank_two_ranks_and_flow_sampling(tmp_path):
     two = _cli(["--num_sampling_steps", "10"], tmp_path / "b", ranks=2)
     assert two.returncode == 0, two.stdout[-1500:] + two.stderr[-3000:]
     assert "done: 16 structures on 2 GPU(s)" in two.stdout
+    assert "ranks=2 backend=gloo" in two.stdout and "equal on every rank" in two.stdout
+    # only rank 0 loaded weights, the noise of a batch is a function of the batch alone: the files of the 2-rank run
+    # are the 1-rank run's bit for bit
+    out_two = os.path.join(tmp_path, "b", "logs", "generated_samples_0_best", "clitest_PED")
+    assert sorted(f for f in os.listdir(out_two) if f.endswith(".npy")) == [f for f in files if f.endswith(".npy")]
+    for f in (f for f in files if f.endswith(".npy")):
+        assert np.array_equal(np.load(os.path.join(out_dir, f)), np.load(os.path.join(out_two, f))), \
+            f"{f}: the 2-rank run's coordinates differ from the 1-rank run's"
     (tmp_path / "c").mkdir()
     fm = _cli(["--model", "fm", "--method", "euler", "--steps", "6"], tmp_path / "c")
     assert fm.returncode == 0, fm.stdout[-1500:] + fm.stderr[-3000:]
