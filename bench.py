@@ -231,31 +231,33 @@ def cpu_model():
 
 
 def cpu_baseline(cfg_name):
-    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample: 4 frames of
-    the L=87 protein, 20 of the 100 DDPM steps run as the reference runs them (batch duplicated,
-    test.py:505; CA features recomputed every step), plus the decoder tail; extrapolated linearly
-    to 100 steps (every step costs the same).  cfg5: the decoder tail alone."""
+    """The CPU oracle (port of the reference's PyTorch-CPU path) on BASELINE.md section 4's sample - the L = 87 protein,
+    10 frames, num_ensemble 1 - with a bounded number of the 100 DDPM steps (10, every step costs the same: extrapolated
+    x10), run as the reference runs them (batch duplicated, test.py:505; CA features recomputed every step), plus the
+    decoder tail in full.  cfg5: the decoder tail alone."""
     from codlad_amd import synth
     from oracle import denoiser as oden, sampler as osam, vae_decode as odec
     torch.set_grad_enabled(False)
-    cores = os.cpu_count() or 1
+    present = os.cpu_count() or 1
+    avail = present
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    cores = min(cores, 16)   # a one-GPU box owns 16 host cores; more threads only oversubscribe
+    cores = min(avail, 16)   # a one-GPU box owns 16 host cores; more threads only oversubscribe
     torch.set_num_threads(cores)
     sd = synth.denoiser_state_dict(WEIGHT_SEED)
     vsd = synth.vqvae_state_dict("N6", "PED", VAE_SEED)
     mean, std = synth.norm_stats("PED", "N6")
-    L, B, Tsub = 87, 4, 20
+    L, B, Tsub = 87, 10, 10
     prot = synth.make_protein(L, 1001, n_frames=B)
     batch = synth.make_batch(prot)
     cg_z, cg_xyz, mask = oden.batch_to_dense(batch)
     dup = lambda t: torch.cat([t, t])  # noqa: E731
     z = synth.gaussian((2 * B, L, 3), 1)
     eps = synth.gaussian((Tsub, 2 * B, L, 3), 2)
-    common = {"unit": "structures/s", "cores": cores, "kind": "port", "cpu_model": cpu_model()}
+    common = {"unit": "structures/s", "cores": cores, "cores_present": present, "cores_available": avail,
+              "kind": "port", "cpu_model": cpu_model()}
 
     def decode(x):
         t0 = time.perf_counter()
@@ -268,8 +270,8 @@ def cpu_baseline(cfg_name):
         reps = 20
         t_dec = sum(decode(z[:B]) for _ in range(reps)) / reps
         return dict(common, value=B / t_dec,
-                    sample=f"oracle (PyTorch-CPU fp32, {cores} threads): decoder tail only (de-normalise + VQ + "
-                           f"IC_Decoder + ic_to_xyz) on L=87, {B} frames, mean of {reps} runs: {t_dec * 1e3:.1f} ms")
+                    sample=f"oracle (PyTorch-CPU fp32, {cores} of {present} hardware threads): decoder tail only (de-normalise "
+                           f"+ VQ + IC_Decoder + ic_to_xyz) on L=87, {B} frames, mean of {reps} runs: {t_dec * 1e3:.1f} ms")
     t0 = time.perf_counter()
     x = osam.p_sample_loop(sd, Tsub, z, eps, dup(cg_xyz), dup(cg_z), dup(mask))
     t_loop = time.perf_counter() - t0
@@ -282,9 +284,10 @@ def cpu_baseline(cfg_name):
     t_dedup = time.perf_counter() - t0
     dedup = 1.0 / ((t_dedup * (T_STEPS / Tsub) + t_dec) / B)
     return dict(common, value=1.0 / per_struct, value_deduplicated=dedup,
-                sample=f"oracle (PyTorch-CPU fp32, {cores} threads): L=87, {B} frames, {Tsub} of {T_STEPS} DDPM steps "
-                       f"as the reference runs them (2x duplicated batch, features recomputed per step) + decode, "
-                       f"extrapolated x{T_STEPS // Tsub}; {t_loop:.2f}s loop + {t_dec:.3f}s decode")
+                sample=f"oracle (PyTorch-CPU fp32, {cores} of {present} hardware threads): BASELINE.md 4's sample - L=87, {B} "
+                       f"frames, ens 1 - {Tsub} of {T_STEPS} DDPM steps as the reference runs them (2x duplicated batch, "
+                       f"features recomputed per step) + decode in full, loop extrapolated x{T_STEPS // Tsub}; "
+                       f"{t_loop:.2f}s loop + {t_dec:.3f}s decode")
 
 
 def committed_traffic(cfg_name, precision):

@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 8   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 9   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -66,6 +66,14 @@ class DecoderWeights(C.Structure):
                [(n, P) for n in ("fin1_w", "fin1_b", "fin3_w", "fin3_b")]
 
 
+class TpConvArgs(C.Structure):
+    _fields_ = [("ptr", P), ("snd", P), ("n_recv", C.c_int32), ("xyz_recv", P), ("xyz_snd", P), ("typ_recv", P),
+                ("typ_snd", P), ("r_sign", C.c_float), ("smear_stop", C.c_float), ("emb0_w", P), ("emb0_b", P),
+                ("emb3_w", P), ("emb3_b", P), ("emb_in", C.c_int32), ("h_recv", P), ("d_recv", C.c_int32), ("h_snd", P),
+                ("d_snd", C.c_int32), ("attr_recv_first", C.c_int32), ("fc0_w", P), ("fc0_b", P), ("fc3_w", P),
+                ("fc3_b", P), ("depth", C.c_int32), ("out", P), ("accumulate", C.c_int32), ("group", C.c_int32)]
+
+
 class MetricInputs(C.Structure):
     _fields_ = [("xyz_recon", P), ("xyz", P), ("n_atoms", C.c_int64),
                 ("edge_list", P), ("n_edges", C.c_int64), ("clash_list", P), ("n_clash", C.c_int64),
@@ -102,6 +110,11 @@ _SIGS = {
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, C.c_int, P]),
+    "codlad_tp_conv": (C.c_int, [C.POINTER(TpConvArgs), P]),
+    "codlad_tp_conv_args_size": (C.c_int, []),
+    "codlad_mlp_rows": (C.c_int, [P, C.c_int, C.c_int, P, P, C.c_int, P, P, C.c_int, C.c_int, C.c_int, P, P]),
+    "codlad_bead_mean": (C.c_int, [P, P, P, P, C.c_int, P, P]),
+    "codlad_embed_rows": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),
     "codlad_selftest_gemm128": (C.c_int, [P, P, P, C.c_int, C.c_int, P, P]),
     "codlad_selftest_gemm128_h": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
 }
@@ -128,7 +141,7 @@ def lib():
     return _lib
 
 
-OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES = 0, 1      # CODLAD_OPT_* of include/codlad_hip.h
+OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_LOOP_GRAPH_MAX_NODES, OPT_DEC_EDGE_VARIANT = 0, 1, 2, 3   # CODLAD_OPT_* of include/codlad_hip.h
 
 
 def set_option(option, value):

@@ -11,12 +11,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
 SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_tile_kernels.hip",
            "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
-           "ic_decoder_kernels.hip", "metrics_kernels.hip"]
+           "ic_decoder_kernels.hip", "encoder_kernels.hip", "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
 # and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
 EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"],
                "ic_decoder_kernels.hip": ["-ffp-contract=off"],
-               "metrics_kernels.hip": ["-ffp-contract=off"],
+               "metrics_kernels.hip": ["-ffp-contract=off"], "encoder_kernels.hip": ["-ffp-contract=off"],
                # SLP packing of the shuffle-reduction adds blocks their fusion into v_add_f32_dpp;
                # the packed math that pays (GELU) is written out explicitly in common.h
                # -fno-honor-nans: min/max on MFMA results otherwise get a canonicalising v_max x,x

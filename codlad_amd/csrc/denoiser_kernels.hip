@@ -584,7 +584,7 @@ static void launch_node_hw(bool upd, const NodeArgs &na, hipStream_t st) {
 }
 
 // Jobs of up to CODLAD_NODEQ_MAX_TILES 32-node tiles take the quarter kernel (one tile per 4-wave workgroup).
-static int g_options[CODLAD_N_OPTIONS] = {-1, -1, -1, -1};
+static int g_options[CODLAD_N_OPTIONS] = {-1, -1, -1, -1, -1, -1, -1, -1};
 static int option_or(int opt, const char *env, int dflt) {
     if (g_options[opt] < 0) {
         const char *e = getenv(env);
@@ -599,6 +599,7 @@ extern "C" int codlad_set_option(int option, int value) {
 }
 static int edge_tile_max_nodes() { return option_or(CODLAD_OPT_EDGE_TILE_MAX_NODES, "CODLAD_EDGE_TILE_MAX_NODES", 1 << 30); }
 static int nodeq_max_tiles() { return option_or(CODLAD_OPT_NODEQ_MAX_TILES, "CODLAD_NODEQ_MAX_TILES", 256); }
+int dec_edge_variant() { return option_or(CODLAD_OPT_DEC_EDGE_VARIANT, "CODLAD_DEC_EDGE_VARIANT", 0); }
 
 // node_wide_kernels.hip
 void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st);

@@ -15,9 +15,14 @@
 // Every sum keeps the order of the reference's ops (fma chain over k, then + bias; edges in scatter order), so
 // results do not depend on which residues share a launch.
 //
-// Scratch (caller's float [M][200], opaque): S^T [40][M] | V^T [40][M] | phi_a [M][40] | phi_b [M][40].
+// Scratch (caller's float [M][200], opaque): S^T [40][M] | V [M][40] | phi_a [M][40] | phi_b [M][40].
+// (V node-major since round 3: a receiving residue's 40 sums leave as one coalesced 160-byte store; feature-major, a wave
+// wrote 40 dwords a column apart - 101 MB of write traffic per launch for 5.7 MB of sums.)
 #include "common.h"
 #include "../../include/codlad_hip.h"
+
+int num_cu();             // denoiser_kernels.hip
+int dec_edge_variant();   // denoiser_kernels.hip: CODLAD_OPT_DEC_EDGE_VARIANT
 
 #define DF 40
 #define PI_F 3.14159265358979323846f
@@ -83,11 +88,13 @@ __global__ __launch_bounds__(256) void dec_init_kernel(codlad_decoder_weights w,
     const Scratch sc = scratch_of(scr, M);
     float *s_col = &col[0][lane], *t_col = &col[DF][lane];
     const int z = cg_z[nn];
-    const float q0 = z_q[3 * nn], q1 = z_q[3 * nn + 1], q2 = z_q[3 * nn + 2];
+    const bool mapped = w.map_out_w != nullptr;          // no map_out (the C2 model): z_q is the 36-wide latent itself
+    const float q0 = mapped ? z_q[3 * nn] : 0.f, q1 = mapped ? z_q[3 * nn + 1] : 0.f, q2 = mapped ? z_q[3 * nn + 2] : 0.f;
     kfloat_p mw = as_uniform(w.map_out_w), mb = as_uniform(w.map_out_b);
     for (int c = wave; c < DF; c += 4) {
         float s;
-        if (c < 36) s = fmaf(q2, mw[3 * c + 2], fmaf(q1, mw[3 * c + 1], q0 * mw[3 * c])) + mb[c];   // F.linear
+        if (c < 36) s = mapped ? fmaf(q2, mw[3 * c + 2], fmaf(q1, mw[3 * c + 1], q0 * mw[3 * c])) + mb[c]   // F.linear
+                               : z_q[(size_t)36 * nn + c];
         else s = w.res_embed[z * 4 + (c - 36)];
         s_col[c * 64] = s;
         if (active) sc.S[(size_t)c * M + n] = s;
@@ -113,7 +120,7 @@ DEV float div_by(float a, float d, float r) {
 #ifndef EDGE_WAVES
 #define EDGE_WAVES 1   // receivers per workgroup: 1 lets 15 waves share a CU's LDS (cfg 5: 1.04 ms against 1.15 with 4)
 #endif
-__global__ __launch_bounds__(64 * EDGE_WAVES) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
+__global__ __launch_bounds__(64 * EDGE_WAVES) void dec_edge_exact_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
                                                       const int32_t *csr_ptr, const int32_t *csr_src, int M,
                                                       float *scr) {
     __shared__ float filt[EDGE_WAVES][64 * WS_STRIDE];
@@ -177,7 +184,149 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void dec_edge_kernel(codlad_decode
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (lane < DF) sc.V[(size_t)lane * M + n] = v;
+    if (lane < DF) sc.V[(size_t)n * DF + lane] = v;
+}
+
+// The same message sum with the 15 -> 40 filter on the matrix pipe (default since round 3; the kernel above stays
+// selectable, CODLAD_OPT_DEC_EDGE_VARIANT = 1).  Per chunk of 64 incoming edges, lane = edge:
+//   * d, the envelope, ONE sine / cosine pair and the three-term recurrence sin((k+1) x) = 2 cos x sin(k x) - sin((k-1) x)
+//     for the 15 radial basis values (x = pi d / cutoff in (0, pi): the recurrence's error grows like k / sin x, which only
+//     matters towards x = pi, where the envelope has already taken the edge's weight to zero) - 15 library sines before;
+//   * u[k] = 16 env rbf[k] (k < 15), u[15] = 16 env: the envelope and the bias ride inside the contraction,
+//     filter[f] env = sum_k W'[f][k] u[k] / 256 with W' = 16 [dist_w | dist_b] (the powers of two keep the fp16 `lo` halves
+//     of these small numbers out of the subnormal range and leave exactly at the end);
+//   * u split into fp16 hi + lo halves (22 bits, as in the denoiser's contractions) and contracted with the equally
+//     split W' by v_mfma_f32_32x32x16_f16, three products per fp32 product, fp32 accumulation: 12 matrix instructions per
+//     64 edges where 600 v_fmac per edge and 40 LDS stores per edge stood before.  The edges are the A operand's rows,
+//     so the result arrives with lane = feature and the 32 edges of a group in registers - the layout the accumulation
+//     wants: per edge one coalesced 128-byte read of the sender's row per lane half and one multiply-add.
+// A lane half sums its own 16 edges of a group in register order, the halves are added at the end: a fixed order per
+// receiving residue, whatever shares the launch (the reference's scatter order is not reproduced bit for bit; nor
+// was it before, to the last ulp of sinf).
+DEV void split_u(f32x2 x, f16x2 &hi, f16x2 &lo) {
+    hi = __builtin_convertvector(x, f16x2);
+    lo = split_lo_pair(hi, x);
+}
+
+__global__ __launch_bounds__(64) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
+                                                       const int32_t *csr_ptr, const int32_t *csr_src, int M,
+                                                       float *scr) {
+    __shared__ int jsh[64];
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const Scratch sc = scratch_of(scr, M);
+    const float *phi_in = sc.phi[blk & 1];
+    // B operand: lane (feature 32 b + c, k group h) holds W'[feature][8 h .. 8 h + 7], split; features >= 40 are zero
+    f16x8 whi[2], wlo[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int f = 32 * b + c;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 v = {0.f, 0.f};
+            if (f < DF) {
+                const int k0 = 8 * h + i;
+                v.x = 16.0f * w.dist_w[blk][f * 15 + k0];                                  // k0 <= 14
+                v.y = 16.0f * (k0 + 1 < 15 ? w.dist_w[blk][f * 15 + k0 + 1] : w.dist_b[blk][f]);
+            }
+            f16x2 hh, ll;
+            split_u(v, hh, ll);
+            whi[b][i] = hh.x; whi[b][i + 1] = hh.y;
+            wlo[b][i] = ll.x; wlo[b][i + 1] = ll.y;
+        }
+    }
+    for (int n = blockIdx.x; n < M; n += gridDim.x) {          // wave-uniform
+        const float xi = cg_xyz[3 * n], yi = cg_xyz[3 * n + 1], zi = cg_xyz[3 * n + 2];
+        const int e0 = __builtin_amdgcn_readfirstlane(csr_ptr[n]), e1 = __builtin_amdgcn_readfirstlane(csr_ptr[n + 1]);
+        float v0 = 0.f, v1 = 0.f;                              // features c (block 0) and 32 + c (block 1, c < 8)
+        for (int base = e0; base < e1; base += 64) {
+            const int cnt = e1 - base < 64 ? e1 - base : 64;
+            const bool live = lane < cnt;
+            const int j = live ? csr_src[base + lane] : n;
+            // preprocess_r (gcn_nn.py:66-70): eps added per component
+            const float rx = cg_xyz[3 * j] - xi, ry = cg_xyz[3 * j + 1] - yi, rz = cg_xyz[3 * j + 2] - zi;
+            const float d = sqrtf(((rx * rx + 1e-8f) + (ry * ry + 1e-8f)) + (rz * rz + 1e-8f));
+            // CosineEnvelope and PainnRadialBasis (gcn_nn.py:231-271): sin(n pi d / cutoff) / d, both 0 beyond the cutoff
+            const float x = (PI_F / CG_CUTOFF) * d;
+            float s1, c1;
+            sincosf(x, &s1, &c1);
+            const bool inside = live && d < CG_CUTOFF;
+            const float env16 = inside ? 8.0f * (c1 + 1.0f) : 0.f;            // 16 * 0.5 (cos + 1)
+            const float g = env16 * refined_rcp(d);                          // 16 env / d
+            const float two_c = c1 + c1;
+            float sk = s1, skm = 0.f;
+            f16x8 ahi[2], alo[2];                                            // k 0-7, k 8-15 of this lane's edge
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                f32x2 u;
+                u.x = sk * g;                                                // sin((k+1) x) / d, enveloped
+                float sn = fmaf(two_c, sk, -skm);
+                skm = sk; sk = sn;
+                if (k + 1 < 15) {
+                    u.y = sk * g;
+                    sn = fmaf(two_c, sk, -skm);
+                    skm = sk; sk = sn;
+                } else {
+                    u.y = env16;                                             // the bias column
+                }
+                f16x2 hh, ll;
+                split_u(u, hh, ll);
+                ahi[k >> 3][k & 7] = hh.x; ahi[k >> 3][(k & 7) + 1] = hh.y;
+                alo[k >> 3][k & 7] = ll.x; alo[k >> 3][(k & 7) + 1] = ll.y;
+            }
+            // A operand of edge group g (edges 32 g .. 32 g + 31): lanes 0-31 its k 0-7, lanes 32-63 its k 8-15.  Lanes
+            // 0-31 hold group 0's edges, lanes 32-63 group 1's: swap the upper half of the k 0-7 registers with the lower
+            // half of the k 8-15 registers (v_permlane32_swap).
+            u32x4 a0h = __builtin_bit_cast(u32x4, ahi[0]), a1h = __builtin_bit_cast(u32x4, ahi[1]);
+            u32x4 a0l = __builtin_bit_cast(u32x4, alo[0]), a1l = __builtin_bit_cast(u32x4, alo[1]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                auto r = __builtin_amdgcn_permlane32_swap(a0h[q], a1h[q], false, false);
+                a0h[q] = r[0]; a1h[q] = r[1];
+                auto t = __builtin_amdgcn_permlane32_swap(a0l[q], a1l[q], false, false);
+                a0l[q] = t[0]; a1l[q] = t[1];
+            }
+            const f16x8 Ahi[2] = {as_f16x8(a0h), as_f16x8(a1h)}, Alo[2] = {as_f16x8(a0l), as_f16x8(a1l)};
+            jsh[lane] = j;
+            const int groups = cnt > 32 ? 2 : 1;                             // wave-uniform
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                if (gq >= groups) break;
+                f32x16 D0, D1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D0[r] = D1[r] = 0.f;
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[gq], wlo[0], D0, 0, 0, 0);
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[gq], whi[0], D0, 0, 0, 0);
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[gq], whi[0], D0, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[gq], wlo[1], D1, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[gq], whi[1], D1, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[gq], whi[1], D1, 0, 0, 0);
+                // register r of lane half h = edge 32 gq + (r & 3) + 8 (r >> 2) + 4 h; edges beyond cnt carry u = 0
+                int jj[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) jj[r] = jsh[32 * gq + (r & 3) + 8 * (r >> 2) + 4 * h];
+                float ph0[16], ph1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float *row = phi_in + (size_t)jj[r] * DF;
+                    ph0[r] = row[c];
+                    ph1[r] = c < 8 ? row[32 + c] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v0 = fmaf(ph0[r], D0[r], v0);
+                    v1 = fmaf(ph1[r], D1[r], v1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                                 // jsh is rewritten by the next chunk
+        }
+        v0 += __shfl_xor(v0, 32, 64);
+        v1 += __shfl_xor(v1, 32, 64);
+        if (h == 0) {
+            float *out = sc.V + (size_t)n * DF;
+            out[c] = v0 * 0.00390625f;                                       // 2^-8: the two factors of 16
+            if (c < 8) out[32 + c] = v1 * 0.00390625f;
+        }
+    }
 }
 
 // S += dense_blocks[blk](V)  (Sequential(swish, Linear, swish, Linear), vae_model.py:365-369, 489), phi for blk + 1
@@ -188,7 +337,13 @@ __global__ __launch_bounds__(256) void dec_dense_kernel(codlad_decoder_weights w
     const int nn = active ? n : M - 1;
     const Scratch sc = scratch_of(scr, M);
     float *a_col = &col[0][lane], *t_col = &col[DF][lane], *s_col = &col[2 * DF][lane];
-    for (int c = wave; c < DF; c += 4) a_col[c * 64] = swishf(sc.V[(size_t)c * M + nn]);
+    {   // the workgroup's 64 x 40 sums are one contiguous block of V: coalesced dword reads, transposed into the columns
+        const size_t first = (size_t)blockIdx.x * 64 * DF, total = (size_t)M * DF;
+        for (int i = threadIdx.x; i < 64 * DF; i += 256) {
+            const float v = first + i < total ? sc.V[first + i] : 0.f;
+            col[i % DF][i / DF] = swishf(v);
+        }
+    }
     __syncthreads();
     wg_dense<DF>(w.dense1_w[blk], w.dense1_b[blk], DF, a_col, wave, [&](int c, float v) { t_col[c * 64] = swishf(v); });
     __syncthreads();
@@ -283,9 +438,12 @@ extern "C" int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_
     CODLAD_REQUIRE(M > 0, "M must be positive");
     hipStream_t st = (hipStream_t)stream;
     const dim3 per_lane((M + 63) / 64), per_wave((M + EDGE_WAVES - 1) / EDGE_WAVES), block(256);
+    const int edge_grid = M < 12 * num_cu() ? M : 12 * num_cu();    // persistent waves, three per SIMD
+    const bool exact = dec_edge_variant() == 1;
     hipLaunchKernelGGL(dec_init_kernel, per_lane, block, 0, st, *w, z_q, cg_z, M, scratch);
     for (int blk = 0; blk < 4; ++blk) {
-        hipLaunchKernelGGL(dec_edge_kernel, per_wave, dim3(64 * EDGE_WAVES), 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
+        if (exact) hipLaunchKernelGGL(dec_edge_exact_kernel, per_wave, dim3(64 * EDGE_WAVES), 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
+        else hipLaunchKernelGGL(dec_edge_kernel, dim3(edge_grid), dim3(64), 0, st, *w, blk, cg_xyz, csr_ptr, csr_src, M, scratch);
         hipLaunchKernelGGL(dec_dense_kernel, per_lane, block, 0, st, *w, blk, M, scratch);
     }
     if (w->angle) hipLaunchKernelGGL(dec_heads_kernel<true>, per_lane, block, 0, st, *w, cg_z, M, scratch, ic_out);

@@ -335,6 +335,86 @@ def make_batch(protein, frame_ids=None):
     }
 
 
+# ----------------------------------------------------------------------------
+# e3nn encoder / prior
+# ----------------------------------------------------------------------------
+TP_WEIGHT_NUMEL = (192, 288, 384)     # FullyConnectedTensorProduct weight counts of the three conv depths
+
+
+def _conv_stack(rng, sd, name, n_layers=3):
+    for l in range(n_layers):
+        _linear(rng, sd, f"{name}.{l}.fc.0", 36, 36)
+        _linear(rng, sd, f"{name}.{l}.fc.3", TP_WEIGHT_NUMEL[l], 36)
+
+
+def _edge_embedding(rng, sd, name, n_in):
+    _linear(rng, sd, f"{name}.0", 12, n_in)
+    _linear(rng, sd, f"{name}.3", 12, 12)
+
+
+def prior_state_dict(seed=777):
+    """e3nnPrior tensors with the reference's key layout (models/vae_model.py:204-243; the shipped C2 checkpoint's
+    `prior_net.*` without e3nn's own buffers)."""
+    rng = _rng(seed)
+    sd = OrderedDict()
+    sd["cg_node_embedding.weight"] = _t(rng.standard_normal((30, 12)))
+    _edge_embedding(rng, sd, "cg_edge_embedding", 14)
+    _conv_stack(rng, sd, "cg_conv_layers")
+    for head in ("mu", "sigma"):
+        _linear(rng, sd, f"{head}.0", 36, 48)
+        _linear(rng, sd, f"{head}.2", 36, 36)
+    return sd
+
+
+def encoder_state_dict(seed=778):
+    """e3nnEncoder tensors with the reference's key layout (models/vae_model.py:21-107)."""
+    rng = _rng(seed)
+    sd = OrderedDict()
+    sd["atom_node_embedding.weight"] = _t(rng.standard_normal((30, 12)))
+    sd["cg_node_embedding.weight"] = _t(rng.standard_normal((30, 12)))
+    _edge_embedding(rng, sd, "atom_edge_embedding", 14)
+    _edge_embedding(rng, sd, "cg_edge_embedding", 14)
+    _edge_embedding(rng, sd, "cross_edge_embedding", 8)
+    for name in ("atom_conv_layers", "cg_conv_layers", "cg_to_atom_conv_layers", "atom_to_cg_conv_layers"):
+        _conv_stack(rng, sd, name)
+    _linear(rng, sd, "dense.0", 36, 84)
+    _linear(rng, sd, "dense.2", 36, 36)
+    return sd
+
+
+_ELEMENT_Z = {"C": 6, "N": 7, "O": 8, "S": 16, "P": 15}
+
+
+def make_atoms(protein, frame_ids=None, seed=0, atom_cutoff=9.0):
+    """All-atom side of a batch, as the reference's CG_collate carries it for the encoder (utils/dataset_module.py:259-295):
+    `nxyz` [n_atoms, 4] (atomic number, xyz), `CG_mapping` [n_atoms] (bead of every atom, batch offset added),
+    `nbr_list` [E, 2] (atom pairs j > i within atom_cutoff, batch offset added), `num_atoms` [B].  Coordinates are
+    synthetic: CA on the bead, the residue's other heavy atoms scattered 1-3 A around it (seeded)."""
+    frames = protein["xyz_full"]
+    if frame_ids is None:
+        frame_ids = range(frames.shape[0])
+    L = protein["n_cg"]
+    names = [IDX2THR[int(z)] for z in protein["z_full"][1:-1]]
+    atoms = [(r, a) for r, nm in enumerate(names) for a in PDB_ATOM_ORDER[nm]]
+    zs = torch.tensor([_ELEMENT_Z[a[0]] for _r, a in atoms], dtype=torch.float32)
+    res = torch.tensor([r for r, _a in atoms], dtype=torch.int64)
+    n = len(atoms)
+    off = _t(_rng(5000 + seed).standard_normal((n, 3))) * 1.2
+    off[[i for i, (_r, a) in enumerate(atoms) if a == "CA"]] = 0.0
+    nxyz, mapping, nbr, num = [], [], [], []
+    for b, f in enumerate(frame_ids):
+        ca = torch.from_numpy(frames[f])[1:-1].float()
+        xyz = ca[res] + off
+        nxyz.append(torch.cat([zs[:, None], xyz], 1))
+        mapping.append(res + b * L)
+        d = (xyz[:, None] - xyz[None]).pow(2).sum(-1).sqrt()
+        m = torch.triu(d <= atom_cutoff, diagonal=1)
+        nbr.append(torch.nonzero(m) + b * n)
+        num.append(n)
+    return {"nxyz": torch.cat(nxyz, 0), "CG_mapping": torch.cat(mapping, 0), "nbr_list": torch.cat(nbr, 0),
+            "num_atoms": torch.tensor(num, dtype=torch.int64)}
+
+
 def gaussian(shape, seed):
     return _t(_rng(seed).standard_normal(shape))
 

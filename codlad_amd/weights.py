@@ -295,7 +295,8 @@ def decoder_tensors(sd):
     p = "equivaraintconv."
     angle = (p + "sidechain_angle.1.weight") in sd
     t = OrderedDict()
-    t["map_out_w"], t["map_out_b"] = g("map_out.weight"), g("map_out.bias")
+    if "map_out.weight" in sd:        # VQ-VAE (N6 / K3 / K4): 3 -> 36; the C2 model decodes its 36-wide latent as it is
+        t["map_out_w"], t["map_out_b"] = g("map_out.weight"), g("map_out.bias")
     t["res_embed"] = g(p + "res_embed.weight")
     for i in range(4):
         m = f"{p}message_blocks.{i}."

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 8
+#define CODLAD_ABI_VERSION 9
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -255,7 +255,8 @@ typedef struct {
 } codlad_decoder_weights;
 
 /* Row 9: VAE.decoder = map_out + IC_Decoder[_angle].forward (vae_model.py:759-764, 375-412, 467-503).
- * z_q [M][3], cg_z int32 [M], cg_xyz [M][3]; directed CG graph in CSR over receiving node:
+ * z_q [M][3] (w->map_out_w given: N6 / K3 / K4) or [M][36] (map_out_w NULL: the C2 model, whose IC decoder takes the
+ * 36-wide latent as it is, vae_model.py:556-561), cg_z int32 [M], cg_xyz [M][3]; directed CG graph in CSR over receiving node:
  * csr_ptr int32 [M+1], csr_src int32 [E_dir] (sending node of each incoming edge, flat index).
  * scratch: float [M][200].  ic_out [M][13][3]. */
 int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_q, const int32_t *cg_z,
@@ -271,6 +272,54 @@ int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_q, const in
 int codlad_cg_graph(const float *cg_xyz, const int32_t *sample_range, int M, float cutoff,
                     int32_t *degree, const int32_t *csr_ptr, int32_t *csr_src, void *stream);
 
+/* Next row 8f-1: the e3nn encoder / CG prior in front of the decoder (reference models/vae_model.py:21-311; what
+ * VAE.get_latent_wovq and get_latent_cg run, reference test.py:495,501).
+ *
+ * codlad_tp_conv = one TensorProductConvLayer.forward (reference models/gcn_nn.py:176-219; residual=False, no batch
+ * norm, reduce='mean') over a set of receiving nodes, fused with everything that feeds it per edge: the distance
+ * r = r_sign * (xyz_snd[s] - xyz_recv[n]), its Gaussian smearing over [0, smear_stop] (8 centres, gcn_nn.py:163-173),
+ * the edge-embedding MLP Linear(emb_in, 12) -> ReLU -> Linear(12, 12) on [type_recv, type_snd, 0, 0, 0, 0, smearing]
+ * (emb_in 14; vae_model.py:164-194) or on the smearing alone (emb_in 8: the atom <-> bead cross graph, :196-201), the
+ * real spherical harmonics of r up to l = 2 ('component' normalisation), fc = Linear(36, 36) -> ReLU ->
+ * Linear(36, weight_numel) on [edge embedding | h[.., :12] | h[.., :12]] and o3.FullyConnectedTensorProduct(irreps of
+ * `depth`, 1x0e + 1x1o + 1x2e, irreps of depth + 1) restated from e3nn 0.5.1's definition (e3nn is not part of the
+ * reference tree: parity unpinned except for the Wigner symbols, see oracle/e3nn_lite.py).
+ *   feature layout of depth d: [12x0e | 4x1o | 4x1e | 12x0o] truncated to 12 (d + 1) floats, vectors as (u, xyz);
+ *   ptr int32 [n_recv + 1], snd int32 [E]: the receivers' CSR (edges of receiver n: ptr[n] .. ptr[n+1]), snd = the
+ *     node whose features h_snd travel along the edge (e3nn's edge_dst; the receiver is its edge_src);
+ *   attr_recv_first: 1 = fc sees [e | h_recv[:12] | h_snd[:12]] (intra graphs, bead -> atom), 0 = [e | h_snd | h_recv]
+ *     (atom -> bead: reference vae_model.py:140-142 passes the same concatenation to both cross directions);
+ *   out [n_recv][12 (depth + 2)]: accumulate 0: out = pad(h_recv) + mean, 1: out += mean (the layer's second update);
+ *   group: lanes per receiving node (64, 16 or 1: pick >= the typical degree; any degree is correct with any group). */
+typedef struct {
+    const int32_t *ptr, *snd;
+    int32_t n_recv;
+    const float *xyz_recv, *xyz_snd;       /* [n][3] */
+    const float *typ_recv, *typ_snd;       /* node types as floats (emb_in 14) or NULL (emb_in 8) */
+    float r_sign, smear_stop;
+    const float *emb0_w, *emb0_b, *emb3_w, *emb3_b;
+    int32_t emb_in;
+    const float *h_recv; int32_t d_recv;   /* receiving nodes' features, row stride d_recv (>= 12) */
+    const float *h_snd; int32_t d_snd;     /* sending nodes' features, row stride = width of `depth` */
+    int32_t attr_recv_first;
+    const float *fc0_w, *fc0_b, *fc3_w, *fc3_b;
+    int32_t depth;                         /* 0, 1, 2 */
+    float *out;
+    int32_t accumulate, group;
+} codlad_tp_conv_args;
+int codlad_tp_conv(const codlad_tp_conv_args *args, void *stream);
+int codlad_tp_conv_args_size(void);      /* sizeof(codlad_tp_conv_args), for bindings to check their layout */
+
+/* y[i] = W2 act(W1 x[i] + b1) + b2 (hidden <= 36; hidden 0: y = W2 x + b2), act 0 tanh / 1 relu, in_dim 84 / 48 / 36,
+ * out_dim <= 36; mode 1: y = 1e-9 + exp(y / 2) (the prior's H_sigma, vae_model.py:263-265). */
+int codlad_mlp_rows(const float *x, int n, int in_dim, const float *w1, const float *b1, int hidden, const float *w2,
+                    const float *b2, int out_dim, int act, int mode, float *y, void *stream);
+/* node[I] = [mean of h_atom over the atoms of bead I (48) | h_cg[I] (36)]  (vae_model.py:158-160) */
+int codlad_bead_mean(const float *h_atom, const float *h_cg, const int32_t *bead_ptr, const int32_t *bead_atoms,
+                     int n_cg, float *node, void *stream);
+/* out[i] = table[idx[i]] (nn.Embedding rows of `width` floats) */
+int codlad_embed_rows(const float *table, const int32_t *idx, int n, int width, float *out, void *stream);
+
 /* Row 10: ic_to_xyz (utils/utils_ic.py:242-268).  ca_full [B][L+2][3] (flanking residues
  * included), ic [B][L][13][3], orders int32 [10][L][3] (atom_orders), slot_to_out int32 [L*14]
  * (output atom index of each residue slot, -1 = slot unused; derived from info's
@@ -285,11 +334,15 @@ int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *order
  *                                "quarter" kernel (one tile per 4-wave workgroup), larger ones on the streaming one
  *   CODLAD_OPT_EDGE_TILE_MAX_NODES  jobs of up to this many nodes deal the edge kernels' work out per 32-edge
  *                                tile instead of per node (twice the waves for the same work)
- *   CODLAD_OPT_LOOP_GRAPH_MAX_NODES  reserved */
+ *   CODLAD_OPT_LOOP_GRAPH_MAX_NODES  reserved
+ *   CODLAD_OPT_DEC_EDGE_VARIANT  IC decoder messages: 0 = one sine / cosine + recurrence, 15 -> 40 filter on the f16 matrix
+ *                                pipe (split fp16, fp32-equivalent); 1 = 15 library sines and fp32 FMAs (round-2 kernel).
+ *                                NOT bit-identical to each other (both within the decoder's parity tolerance) */
 #define CODLAD_OPT_NODEQ_MAX_TILES 0
 #define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
 #define CODLAD_OPT_LOOP_GRAPH_MAX_NODES 2
-#define CODLAD_N_OPTIONS 4
+#define CODLAD_OPT_DEC_EDGE_VARIANT 3
+#define CODLAD_N_OPTIONS 8
 int codlad_set_option(int option, int value);
 
 /* Measurement aid for bench.py (not part of the reference's interface): while enabled, every edge-kernel launch made

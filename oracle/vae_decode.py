@@ -46,9 +46,11 @@ def _seq(sd, p, x):
     return _lin(sd, f"{p}.3", _swish(_lin(sd, f"{p}.1", _swish(x))))
 
 
-def ic_decode(sd, z_q_flat, cg_z, cg_xyz, nbr_undirected, angle=False, p="equivaraintconv"):
-    """z_q_flat [M,3] (restore_shape'd), cg_z [M], cg_xyz [M,3], nbr [E,2] j>i -> ic [M,13,3]."""
-    S = _lin(sd, "map_out", z_q_flat)                                   # vae_model.py:762
+def ic_decode(sd, z_q_flat, cg_z, cg_xyz, nbr_undirected, angle=False, p="equivaraintconv", latent_is_state=False):
+    """z_q_flat [M,3] (restore_shape'd), cg_z [M], cg_xyz [M,3], nbr [E,2] j>i -> ic [M,13,3].
+    latent_is_state: the C2 model (GenZProt.decoder, vae_model.py:556-561) hands its 36-wide latent to the IC decoder
+    as it is - no map_out."""
+    S = z_q_flat if latent_is_state else _lin(sd, "map_out", z_q_flat)  # vae_model.py:762
     nb = nbr_undirected
     gtr_ij = bool((nb[:, 0] > nb[:, 1]).any())
     gtr_ji = bool((nb[:, 1] > nb[:, 0]).any())

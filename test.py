@@ -57,14 +57,37 @@ def load_denoiser(args, device, load=True):
 
 
 def load_vae(args, device, load=True):
+    """The VQ-VAE; with its e3nn encoder when the run needs it (`--experiment recon` encodes the batch's atoms)."""
+    enc = args.experiment == "recon"
     if not load:
-        return build_vae(args.vae_type).to(device).eval()
+        return build_vae(args.vae_type, with_encoder=enc).to(device).eval()
     if args.synthetic_weights:
-        vae = build_vae(args.vae_type)
-        load_decoder_state(vae, synth.vqvae_state_dict(args.vae_type, args.data_type, 4321))
+        vae = build_vae(args.vae_type, with_encoder=enc)
+        sd = synth.vqvae_state_dict(args.vae_type, args.data_type, 4321)
+        if enc:
+            sd.update({"encoder." + k: v for k, v in synth.encoder_state_dict(778).items()})
+            sd.update({k: v for k, v in vae.state_dict().items() if k.endswith(".offset")})
+        load_decoder_state(vae, sd)
         return vae.to(device).eval()
-    vae, _params = get_vae_model(args.vae_type, device=device, modelnum=args.modelnum)
+    vae, _params = get_vae_model(args.vae_type, device=device, modelnum=args.modelnum, with_encoder=enc)
     return vae.to(device).eval()
+
+
+def load_cvae(args, device, load=True):
+    """The conditional VAE (`--cvae_type C2`, reference test.py:317-320): its CG prior conditions `--cond` models and IS
+    the generator of `--experiment genzprot`."""
+    if not load:
+        return build_vae(args.cvae_type).to(device).eval()
+    if args.synthetic_weights:
+        cvae = build_vae(args.cvae_type)
+        sd = {k: v for k, v in cvae.state_dict().items()}
+        sd.update({"prior_net." + k: v for k, v in synth.prior_state_dict(777).items()})
+        sd.update({"encoder." + k: v for k, v in synth.encoder_state_dict(779).items()})
+        sd.update(synth.decoder_state_dict(4322, angle=False))
+        load_decoder_state(cvae, sd)
+        return cvae.to(device).eval()
+    cvae, _params = get_vae_model(args.cvae_type, device=device)
+    return cvae.to(device).eval()
 
 
 _TOPOLOGY = {}                     # output name -> (residue names, atom names per residue) where known (--save_pdb)
@@ -96,7 +119,10 @@ def iter_batches(args):
             for c, (a, b) in enumerate(plan):
                 out = output_name(f"synthetic_L{L}", c, len(plan))
                 _TOPOLOGY[out] = (names, [synth.PDB_ATOM_ORDER[nm] for nm in names])
-                yield out, synth.make_batch(prot, range(a, b)), prot["info"]
+                batch = synth.make_batch(prot, range(a, b))
+                if getattr(args, "experiment", "latent") == "recon":      # the encoder reads the all-atom side of the batch
+                    batch.update(synth.make_atoms(prot, range(a, b), seed=1000 + i))
+                yield out, batch, prot["info"]
         return
     if not args.data_process:
         raise SystemExit("pdb/xtc loading needs mdtraj (out of scope): use --data_process --data_files ... or --synthetic")
@@ -200,7 +226,9 @@ def main(args):
                                   "does not define (dead path)")
     # only rank 0 reads checkpoints; the other ranks receive its weights (reference: one process, test.py:264-286)
     vae = load_vae(args, device, load=rank == 0)
-    model = None
+    model, cvae = None, None
+    if args.experiment == "genzprot":
+        cvae = load_cvae(args, device, load=rank == 0)
     if args.experiment == "latent":
         model = load_denoiser(args, device, load=rank == 0)
         diffusion = None if args.model != "diffusion" else create_diffusion(str(args.num_sampling_steps), noise_schedule=args.noise_schedule,
@@ -208,11 +236,11 @@ def main(args):
                                      rescale_learned_sigmas=args.rescale_learned_sigmas,
                                      # reference test.py:297-303
                                      self_condition=hasattr(model, "self_condition") and args.self_condition)
-    elif args.experiment != "recon":
-        raise NotImplementedError(f"experiment {args.experiment!r}: latent and recon are built")
+    elif args.experiment not in ("recon", "genzprot"):
+        raise NotImplementedError(f"experiment {args.experiment!r}: latent, recon and genzprot are built")
     if world > 1:
         from codlad_amd import parallel
-        mods = [m for m in (model, vae) if m is not None]
+        mods = [m for m in (model, vae, cvae) if m is not None]
         parallel.broadcast_module_state(*mods, src=0)
         # every rank packs the same parameters into its device blobs; prove it (and leave a record of the rank
         # count and backend the collective ran on)
@@ -246,16 +274,21 @@ def main(args):
                 samples = run_sampling(model, args, z, mask=mask, batch=rep)
             samples = get_norm_feature(samples, args.vae_type, norm_channel=args.norm, norm_single=args.norm_single,
                                        norm_in=False, dataname=args.data_type)
+        elif args.experiment == "recon":
+            # reference test.py:501: the VQ-VAE's own encoder on the batch's atoms, un-quantized (latent_decode
+            # quantizes); deterministic, so the E ensemble members of a frame are equal, as in the reference's loop
+            feat = vae.get_latent_wovq(batch)[0]
+            samples = feat.repeat(E, 1, 1)
         else:
-            mean = torch.tensor(synth.NORM_STATS[(args.data_type, args.vae_type)][0], device=device)
-            std = torch.tensor(synth.NORM_STATS[(args.data_type, args.vae_type)][1], device=device)
-            samples = torch.randn(B * E, L, args.latent_size, device=device, generator=gen) * std + mean   # stands in for the encoder
+            # --experiment genzprot (reference test.py:495-498, 559): a sample of the conditional prior per member
+            samples = torch.cat([cvae.get_latent_cg(batch, generator=gen)[0] for _ in range(E)], 0)
+        decoder_model = cvae if args.experiment == "genzprot" else vae
         nres = L + 2
         og = batch["OG_CG_nxyz"].reshape(-1, nres, 4)
         xyz_all = []
         evaluation = Evaluation() if all(k in batch for k in EVAL_KEYS) else None
         for e in range(E):
-            _, ic_recon = vae.latent_decode(samples[e * B:(e + 1) * B], mask[:B], batch)
+            _, ic_recon = decoder_model.latent_decode(samples[e * B:(e + 1) * B], mask[:B], batch)
             xyz_all.append(ic_to_xyz(og, ic_recon.reshape(-1, nres - 2, 13, 3), info))
             if evaluation is not None:                               # reference test.py:589-594, per ensemble member
                 evaluation.add(batch, ic_recon, xyz_all[-1], xyz_all[-1].shape[1])

@@ -65,14 +65,14 @@ def main():
         changed = not torch.equal(before, cfg.den.weights.blob.data)
         assert changed == (rank != 0), "broadcast must overwrite exactly the non-source ranks' blobs"
         # the struct the kernels read must now hold RANK 0's exponents on every rank
-        mine = torch.tensor(exponent_table(cfg.den.weights))
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
+        exps = torch.tensor(exponent_table(cfg.den.weights))
+        every = [torch.zeros_like(exps) for _ in range(world)]
+        dist.all_gather(every, exps)
         assert all(torch.equal(e, every[0]) for e in every), "block exponents differ between ranks after the broadcast"
         if mode != "r1_empty" and rank != 0:
             assert exponent_table(cfg.den.weights) != exp_before, "the test must start rank 1 from OTHER exponents"
         want_nonzero = mode == "r0_envelope"
-        assert (int(mine.abs().sum()) != 0) == want_nonzero
+        assert (int(exps.abs().sum()) != 0) == want_nonzero
         assert cfg.dec.weights.angle == (VAE_TYPE[mode][0] != "N6")
         costs = [parallel.unit_cost(LENGTHS[p]) for p, _f, _m in cfg.units]
         shards = parallel.shard_units(costs, world)
@@ -90,7 +90,7 @@ def main():
                     o += n
                 assert o == flat.size
             out["shard_sizes"] = np.array([len(s) for s in shards])
-            out["exponents"] = mine.numpy()
+            out["exponents"] = exps.numpy()
             np.savez(os.path.join(outdir, "gathered.npz"), **out)
         dist.barrier()
     finally:

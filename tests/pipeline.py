@@ -21,6 +21,7 @@ class Config:
         """denoiser_sd: a state dict instead of the seeded one; no_weights: both engines start EMPTY (a rank that
         waits for rank 0's broadcast), the decoder even with the N6 layout whatever `vae_type` says."""
         self.name, self.T, self.device = name, T, torch.device(device)
+        self.vae_type, self.dataname, self.vae_seed = vae_type, dataname, vae_seed
         if no_weights:
             self.den, self.dec = Denoiser(None, self.device), Decoder(None, self.device)
         else:

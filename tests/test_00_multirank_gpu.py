@@ -133,3 +133,29 @@ def test_cli_single_rank_two_ranks_and_flow_sampling(tmp_path):
     fm = _cli(["--model", "fm", "--method", "euler", "--steps", "6"], tmp_path / "c")
     assert fm.returncode == 0, fm.stdout[-1500:] + fm.stderr[-3000:]
     assert "done: 16 structures on 1 GPU(s)" in fm.stdout
+
+
+@pytest.mark.timeout(900)
+def test_cli_recon_and_genzprot(tmp_path):
+    """`--experiment recon` (the VQ-VAE's e3nn encoder on the batch's atoms -> VQ -> IC decoder -> xyz; BASELINE config 5
+    from atoms) and `--experiment genzprot` (the C2 prior's sample -> C2 IC decoder) through the drop-in CLI; recon is
+    deterministic, so its two ensemble members are equal and a 2-rank run writes the 1-rank run's files."""
+    (tmp_path / "a").mkdir()
+    one = _cli(["--experiment", "recon"], tmp_path / "a")
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-3000:]
+    assert "done: 16 structures on 1 GPU(s)" in one.stdout
+    out_dir = os.path.join(tmp_path, "a", "logs", "generated_samples_0_best", "clitest_PED")
+    xyz = np.load(os.path.join(out_dir, "synthetic_L87_xyz_recon.npy"))
+    assert xyz.shape[:2] == (2, 2) and np.isfinite(xyz).all() and np.array_equal(xyz[0], xyz[1])
+    (tmp_path / "b").mkdir()
+    two = _cli(["--experiment", "recon"], tmp_path / "b", ranks=2)
+    assert two.returncode == 0, two.stdout[-1500:] + two.stderr[-3000:]
+    out_two = os.path.join(tmp_path, "b", "logs", "generated_samples_0_best", "clitest_PED")
+    for f in sorted(os.listdir(out_dir)):
+        assert np.array_equal(np.load(os.path.join(out_dir, f)), np.load(os.path.join(out_two, f))), f
+    (tmp_path / "c").mkdir()
+    gz = _cli(["--experiment", "genzprot"], tmp_path / "c")
+    assert gz.returncode == 0, gz.stdout[-1500:] + gz.stderr[-3000:]
+    assert "done: 16 structures on 1 GPU(s)" in gz.stdout
+    xyz = np.load(os.path.join(tmp_path, "c", "logs", "generated_samples_0_best", "clitest_PED", "synthetic_L46_xyz_recon.npy"))
+    assert np.isfinite(xyz).all() and not np.array_equal(xyz[0], xyz[1])          # members = different prior samples

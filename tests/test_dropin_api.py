@@ -57,7 +57,10 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         create_diffusion("100", predict_xstart=True)
     with pytest.raises(NotImplementedError):
-        build_vae("C2")
+        build_vae("X9")                                                         # N6 / K3 / K4 / C2 exist
+    from codlad_amd.models.vae_model import e3nnPrior
+    with pytest.raises(NotImplementedError):
+        e3nnPrior(device="cpu", n_atom_basis=36, use_second_order_repr=True)    # l = 2 node features are not built
 
 
 def test_cpu_tensors_are_refused_not_silently_computed():
@@ -72,7 +75,11 @@ def test_cpu_tensors_are_refused_not_silently_computed():
     with pytest.raises(RuntimeError, match="MI355X"):
         vae.latent_decode(x, mask, batch)
     with pytest.raises(NotImplementedError):
-        vae.get_latent_cg(batch)
+        vae.get_latent_cg(batch)                                                # a VQ-VAE has no CG prior
+    with pytest.raises(NotImplementedError):
+        vae.get_latent_wovq(batch)                                              # ... and this one was built without encoder
+    with pytest.raises(RuntimeError, match="MI355X"):
+        build_vae("C2").get_latent_cg(batch)                                    # the C2 prior runs on the GPU only
 
 
 def test_create_diffusion_surface():
@@ -102,9 +109,19 @@ def test_vae_checkpoint_layouts(tmp_path):
     d.mkdir()
     torch.save(dict(synth.vqvae_state_dict("N6", "PED", 1)), d / "best_model.pt")
     (d / "modelparams.json").write_text(json.dumps({"cg_cutoff": 21.0, "atom_cutoff": 9.0, "edgeorder": 2}))
-    model, params = get_vae_model("N6", modelpath=str(d), device="cpu", modelnum=999)
+    # a decoder-only file loads into a decoder-only model; the model the reference builds carries the e3nn encoder too
+    model, params = get_vae_model("N6", modelpath=str(d), device="cpu", modelnum=999, with_encoder=False)
     assert params["cg_cutoff"] == 21.0
     assert torch.equal(model.map_out.weight, synth.vqvae_state_dict("N6", "PED", 1)["map_out.weight"])
+    with pytest.raises(RuntimeError, match="missing"):
+        get_vae_model("N6", modelpath=str(d), device="cpu", modelnum=999)
+    full = dict(build_vae("N6", with_encoder=True).state_dict())
+    full.update(synth.vqvae_state_dict("N6", "PED", 1))
+    full.update({"encoder." + k: v for k, v in synth.encoder_state_dict(5).items()})
+    full["encoder.atom_conv_layers.1.tp.output_mask"] = torch.ones(36)        # e3nn's own buffers: skipped
+    torch.save(full, d / "model.pt")
+    model, _ = get_vae_model("N6", modelpath=str(d), device="cpu")
+    assert torch.equal(model.encoder.dense[2].weight, synth.encoder_state_dict(5)["dense.2.weight"])
     # the shipped C2 decoder weights load into IC_Decoder (same module layout)
     w = np.load(cases.npz_path("c2_decoder_weights"))
     vae = build_vae("N6")

@@ -20,7 +20,24 @@ pytestmark = pytest.mark.gpu
 PED_LENGTHS = list(synth.PED_LENGTHS)
 
 
-def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=()):
+def check_decode_against_oracle(cfg, u, x0, idx, xyz):
+    """The decoder tail of unit u against the CPU oracle ON THE HIP PATH'S OWN LATENT (so a code flip at a Voronoi
+    boundary cannot enter): code indices bit-exact, coordinates RMSD <= 1e-4 A."""
+    from oracle import vae_decode as odec
+    p, f, _m = cfg.units[u]
+    prot = cfg.proteins[p]
+    L = prot["n_cg"]
+    batch = synth.make_batch(prot, frame_ids=[f])
+    vsd = synth.vqvae_state_dict(cfg.vae_type, cfg.dataname, cfg.vae_seed)
+    mean, std = synth.norm_stats(cfg.dataname, cfg.vae_type)
+    ridx, ic = odec.latent_decode(vsd, odec.denormalise(x0.cpu()[None], mean, std), batch, angle=cfg.vae_type != "N6")
+    ref = odec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4), ic.reshape(-1, L, 13, 3), prot["info"])
+    assert torch.equal(idx.cpu(), ridx.reshape(-1)), (u, L)
+    rmsd = float(((xyz.cpu() - ref[0]) ** 2).sum(-1).mean().sqrt())
+    assert rmsd < 1e-4, (u, L, rmsd)
+
+
+def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=(), decode_oracle_units=()):
     whole = cfg.run_units(unit_ids)
     again = cfg.run_units(unit_ids)
     for u in unit_ids:                               # deterministic replay
@@ -52,6 +69,8 @@ def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=()):
         got = whole[u][0].cpu()
         err = float((got - ref[0]).abs().max() / ref[0].abs().max())
         assert err < 1e-4, (u, err)
+    for u in list(oracle_units) + list(decode_oracle_units):     # VQ + IC decoder + ic_to_xyz of a unit against the oracle
+        check_decode_against_oracle(cfg, u, *whole[u])
     return whole
 
 
@@ -103,7 +122,12 @@ def test_cfg3_pdb_k3_full_size():
     assert len(lengths) == 64 and min(lengths) >= 50 and max(lengths) <= 400
     cfg = pipeline.Config("cfg3", lengths, n_frames=c["n_frames"], n_ensemble=c["n_ensemble"], vae_type=c["vae_type"],
                           dataname=c["dataname"])
-    check_job(cfg, list(range(64)), n_shards=8, shards_to_run=[0, 5], oracle_units=[int(np.argmin(lengths))])
+    # sampler: the shortest protein against the oracle's 100-step loop; decoder tail (K3 angle decoder): the shortest,
+    # the longest (L = 400) and a median one against the oracle on the HIP latents
+    order = np.argsort(lengths)
+    check_job(cfg, list(range(64)), n_shards=8, shards_to_run=[0, 5], oracle_units=[int(order[0])],
+              decode_oracle_units=[int(order[-1]), int(order[32])])
+    assert lengths[int(order[-1])] == 400
 
 
 def test_cfg4_atlas_k4_one_gpu_share():
@@ -120,4 +144,9 @@ def test_cfg4_atlas_k4_one_gpu_share():
     shards = parallel.shard_units(costs, 8)
     loads = [sum(costs[i] for i in s) for s in shards]
     assert max(loads) / min(loads) < 1.01            # LPT balance across the 8 ranks
-    check_job(cfg, shards[0], n_shards=2, shards_to_run=[1])
+    # decoder tail (K4 angle decoder) of this share's longest and shortest units against the oracle on the HIP latents,
+    # and the 100-step sampler of its shortest
+    by_len = sorted(shards[0], key=lambda u: (lengths[cfg.units[u][0]], u))
+    assert lengths[cfg.units[by_len[-1]][0]] == 505
+    check_job(cfg, shards[0], n_shards=2, shards_to_run=[1], oracle_units=[by_len[0]],
+              decode_oracle_units=[by_len[-1], by_len[len(by_len) // 2]])

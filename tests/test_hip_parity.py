@@ -407,6 +407,31 @@ def test_ic_decode_and_xyz(name):
         assert my_err < 4 * ref_err + 2e-5, (my_err, ref_err)
 
 
+@pytest.mark.parametrize("name", list(cases.DECODER_CASES))
+def test_ic_decode_message_kernel_variants(name):
+    """CODLAD_OPT_DEC_EDGE_VARIANT: the decoder's message sum with the radial basis from one sine / cosine and the
+    15 -> 40 filter on the f16 matrix pipe (0, default) and with 15 library sines and fp32 FMAs (1, the round-2 kernel):
+    both within the golden's tolerance, and close to each other (not bit-identical: different summation order and a
+    22-bit operand split)."""
+    L, B, seed, vae_type = cases.DECODER_CASES[name]
+    prot, batch, latent, dataname = cases.decoder_inputs(L, B, seed, vae_type)
+    dec = Decoder(_vae_sd(vae_type, dataname, False), DEV)
+    _idx, zq, _ = dec.vq(latent.to(DEV), normalised=False)
+    gold = np.load(cases.npz_path(f"g5_decode_{name}"))
+    ics = []
+    for variant in (0, 1):
+        _lib.set_option(_lib.OPT_DEC_EDGE_VARIANT, variant)
+        try:
+            ics.append(dec.ic_decode(zq.reshape(-1, 3), batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:],
+                                     batch["CG_nbr_list"]))
+        finally:
+            _lib.set_option(_lib.OPT_DEC_EDGE_VARIANT, 0)
+        assert rel_err(ics[-1], gold["ic_recon"]) < 2e-5, variant
+    assert rel_err(ics[0], ics[1]) < 1e-5
+    assert torch.equal(ics[0], dec.ic_decode(zq.reshape(-1, 3), batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:],
+                                             batch["CG_nbr_list"]))          # deterministic
+
+
 def test_cg_graph_on_device_equals_reference_neighbour_list():
     """codlad_cg_graph == get_neighbor_list + make_directed + receiver-sorted scatter order."""
     dec = Decoder(synth.vqvae_state_dict("N6", "PED", cases.VAE_SEED), DEV)

@@ -501,6 +501,25 @@ def g7_end_to_end(ref, model):
         os.chdir(cwd)
 
 
+def g14_e3nn_fixtures(ref):
+    """Reference-held DATA that pins the restated e3nn pieces (oracle/e3nn_lite.py): from the shipped C2 checkpoint the
+    trained prior (`prior_net.*`) and the Wigner 3j buffers e3nn itself stored in it; from datasets/miu_and_sigma the
+    per-channel mean / std of that checkpoint's prior latent over the PED set."""
+    print("g14 e3nn fixtures (C2 prior weights, w3j buffers, latent statistics)")
+    c2 = torch.load(os.path.join(ref["root"], "results/Vae_m1_12-23-23_12345/model.pt"), map_location="cpu",
+                    weights_only=True)
+    out = {k: v for k, v in c2.items() if k.startswith("prior_net.") and ".tp." not in k}
+    out["w3j_1_1_1"] = c2["prior_net.cg_conv_layers.1.tp._compiled_main_left_right._w3j_1_1_1"]
+    out["w3j_1_2_1"] = c2["prior_net.cg_conv_layers.1.tp._compiled_main_left_right._w3j_1_2_1"]
+    for l in range(3):
+        out[f"output_mask_{l}"] = c2[f"prior_net.cg_conv_layers.{l}.tp.output_mask"]
+        out[f"weight_numel_{l}"] = torch.tensor(c2[f"prior_net.cg_conv_layers.{l}.fc.3.weight"].shape[0])
+    for nm in ("mean", "std"):
+        out[f"PED_C2_y_{nm}"] = torch.load(os.path.join(ref["root"], f"datasets/miu_and_sigma/PED_C2_y_{nm}.pt"),
+                                           map_location="cpu", weights_only=True)
+    save("c2_prior_e3nn", **{k: v.numpy() for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -541,6 +560,7 @@ def main():
     if want("g11"): g11_validity(ref)
     if want("g12"): g12_flow(ref)
     if want("g13"): g13_info_tables(ref)
+    if want("g14"): g14_e3nn_fixtures(ref)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 
-enum { SAME = 0, ROWS = 1, STREAM = 2, UPD = 3, ROWS_SKEW = 4 };   // ROWS_SKEW: the four 128-byte lines of a row rotated by the row index      // UPD: 16 gathered-row loads + 16 streaming loads (+ stores in place)
+enum { SAME = 0, ROWS = 1, STREAM = 2, UPD = 3, ROWS_SKEW = 4, ROWS2 = 5, UPD2 = 6 };   // ROWS2: two WHOLE rows per instruction (lanes 0-31 one 512-byte row, lanes 32-63 the next); UPD2: UPD with ROWS2 gathers
+   // ROWS_SKEW: the four 128-byte lines of a row rotated by the row index      // UPD: 16 gathered-row loads + 16 streaming loads (+ stores in place)
 
 template <int PATTERN, int NLOAD, bool STORE>
 __global__ __launch_bounds__(512) void k(const float4 *src, float4 *dst, const int *rows, int tiles, size_t tile_f4, float *sink) {
@@ -26,6 +27,8 @@ __global__ __launch_bounds__(512) void k(const float4 *src, float4 *dst, const i
                 const int r = rows[(t * 32 + c) & 4095];
                 p = src + (size_t)r * 32 + ((((i & 15) >> 2) + r) & 3) * 8 + 2 * (i & 3) + h;
             }
+            else if (PATTERN == ROWS2) p = src + (size_t)rows[(t * 32 + 2 * (i & 15) + h) & 4095] * 32 + c;
+            else if (PATTERN == UPD2 && i >= 16) p = dst + (size_t)rows[(t * 32 + 2 * (i & 15) + h) & 4095] * 32 + c;
             else if (PATTERN == ROWS) p = src + (size_t)rows[(t * 32 + c) & 4095] * 32 + 2 * (i & 15) + h;
             else if (PATTERN == UPD && i >= 16) p = dst + (size_t)rows[(t * 32 + c) & 4095] * 32 + 2 * (i & 15) + h;
             else p = src + tile * 1024 + (size_t)(2 * (i & 15) + h) * 32 + c;           // 16 KB per tile, 1 KB per instruction
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(512) void k(const float4 *src, float4 *dst, const i
         if (STORE) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                (PATTERN == UPD ? const_cast<float4 *>(src) : dst)[tile * 1024 + (size_t)(2 * i + h) * 32 + c] = make_float4(acc, v[i % NLOAD].y, v[i % NLOAD].z, acc);
+                ((PATTERN == UPD || PATTERN == UPD2) ? const_cast<float4 *>(src) : dst)[tile * 1024 + (size_t)(2 * i + h) * 32 + c] = make_float4(acc, v[i % NLOAD].y, v[i % NLOAD].z, acc);
         }
     }
     if (acc == 12345.678f) sink[threadIdx.x] = acc;
@@ -79,5 +82,8 @@ int main() {
     run<STREAM, 32, true>("32 loads + 16 stores, streaming", src, dst, rows, n_tiles, sink);
     run<UPD, 32, false>("16 streaming + 16 row loads", src, dst, rows, n_tiles, sink);
     run<UPD, 32, true>("the same + 16 stores in place", src, dst, rows, n_tiles, sink);
+    run<ROWS2, 16, false>("16 loads, 2 whole rows per instruction", src, dst, rows, n_tiles, sink);
+    run<UPD2, 32, false>("16 streaming + 16 whole-row loads", src, dst, rows, n_tiles, sink);
+    run<UPD2, 32, true>("the same + 16 stores in place", src, dst, rows, n_tiles, sink);
     return 0;
 }
