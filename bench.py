@@ -409,11 +409,24 @@ def main():
             n_atoms = sum(c * int(p["info"][0].numel()) for _s, c, p, _ca in wl.groups)
             nbytes = sum(decode_bytes_per_structure(L, 0, 0) for L in wl.job.sample_lens) + 20 * n_atoms + \
                 16 * int(wl.csr[0][-1]) // 2
+            # SURVEY.md 8d prices this configuration against HBM; the tail is arithmetic- and latency-bound, so the same
+            # time is also priced against the fp32 rate: algorithmic FLOP of the decoder (reference vae_model.py:467-503:
+            # per directed CG edge and message block a 15 -> 40 filter, its envelope and a 40-wide multiply-add = 2 (15 40
+            # + 40 + 40) FLOP, four blocks; per residue the 40..53-wide dense layers, ~30 k MAC) and of the VQ scan
+            # (4096 codes x 8 FLOP per residue)
+            n_dir = int(wl.csr[0][-1])
+            alg_flop = 4 * 2 * (15 * 40 + 80) * n_dir + (2 * 30000 + 8 * 4096) * wl.job.n_nodes
             roofline = {"bound": "hbm", "achieved": nbytes / t_dec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": nbytes / t_dec / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "cg_graph + vq + dec_init/edge/dense/heads + ic_to_xyz (the whole decode; its largest kernel, "
-                                  "dec_edge_kernel, is fp32-VALU bound: 16 transcendentals + 600 FMA per CG edge)",
-                        "launch_ms": t_dec * 1e3, "algorithmic_bytes_per_launch": nbytes}
+                                  "dec_edge_kernel: per CG edge one sine / cosine, a 15 -> 40 filter on the f16 matrix pipe "
+                                  "(split fp16) and a gathered 40-wide multiply-add)",
+                        "launch_ms": t_dec * 1e3, "algorithmic_bytes_per_launch": nbytes,
+                        "fp32_compute": {"algorithmic_flop_per_launch": alg_flop, "achieved_tflops": alg_flop / t_dec / 1e12,
+                                         "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                                         "frac": alg_flop / t_dec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                         "note": "algorithmic decoder + VQ FLOP / the same launch time / fp32 vector peak: "
+                                                 "the tail is bound by latency and instruction issue, not by bytes"}}
         else:
             # dominant kernel: layers 1-2 of the encoder message MLP.  Algorithmic 2*(384*128 + 128*128) FLOP per
             # edge (reference protein_mpnn_utils.py:240-243; W3 runs in the node kernel); EXECUTED after the W1

@@ -7,11 +7,13 @@
 // Row 8.  d(z, e) = (|z|^2 + |e|^2) - 2 * dot(z, e), evaluated in exactly the association the
 // reference's CPU path uses so the argmin is bit-identical on identical latents:
 //   |v|^2 = (v0*v0 + v1*v1) + v2*v2 (separately rounded),  dot = fma(z2,e2, fma(z1,e1, z0*e0)).
-// First index wins ties.  A workgroup = 64 latents x 8 waves: the codebook (with |e|^2) sits in LDS, each
-// wave scans one eighth of it (a broadcast read per code), and wave 0 merges the eight (distance, index)
+// First index wins ties.  A workgroup = 64 latents x 16 waves: the codebook (with |e|^2) sits in LDS, each
+// wave scans one sixteenth of it (a broadcast read per code), and wave 0 merges the sixteen (distance, index)
 // candidates in index order with a strict <, which is the first-minimum rule of the sequential scan.
+// (Round 3: 16 waves instead of 8.  Two workgroups fit a CU's LDS either way, so cfg 5's 553 workgroups need a second,
+// nearly empty round on the 512 slots; with twice the waves per workgroup each round takes half as long.)
 // ---------------------------------------------------------------------------------------------
-#define VQ_WAVES 8
+#define VQ_WAVES 16
 __global__ __launch_bounds__(64 * VQ_WAVES) void vq_kernel(const float *x, int n, const float *mean3,
                                                           const float *std3, const float *codebook,
                                                           int n_codes, int64_t *idx, float *z_q,

@@ -208,7 +208,7 @@ DEV void split_u(f32x2 x, f16x2 &hi, f16x2 &lo) {
     lo = split_lo_pair(hi, x);
 }
 
-__global__ __launch_bounds__(64) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
+__global__ __launch_bounds__(64, 4) void dec_edge_kernel(codlad_decoder_weights w, int blk, const float *cg_xyz,
                                                        const int32_t *csr_ptr, const int32_t *csr_src, int M,
                                                        float *scr) {
     __shared__ int jsh[64];
@@ -301,20 +301,25 @@ __global__ __launch_bounds__(64) void dec_edge_kernel(codlad_decoder_weights w, 
                 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[gq], whi[1], D1, 0, 0, 0);
                 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[gq], whi[1], D1, 0, 0, 0);
                 // register r of lane half h = edge 32 gq + (r & 3) + 8 (r >> 2) + 4 h; edges beyond cnt carry u = 0
-                int jj[16];
+                // eight sender rows in flight per lane half (two batches per group: the registers this saves buy a fifth
+                // wave per SIMD, which hides more of the gather's latency than sixteen rows per wave did)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) jj[r] = jsh[32 * gq + (r & 3) + 8 * (r >> 2) + 4 * h];
-                float ph0[16], ph1[16];
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    int jj[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float *row = phi_in + (size_t)jj[r] * DF;
-                    ph0[r] = row[c];
-                    ph1[r] = c < 8 ? row[32 + c] : 0.f;
-                }
+                    for (int r = 0; r < 8; ++r) jj[r] = jsh[32 * gq + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * h];
+                    float ph0[8], ph1[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v0 = fmaf(ph0[r], D0[r], v0);
-                    v1 = fmaf(ph1[r], D1[r], v1);
+                    for (int r = 0; r < 8; ++r) {
+                        const float *row = phi_in + (size_t)jj[r] * DF;
+                        ph0[r] = row[c];
+                        ph1[r] = c < 8 ? row[32 + c] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        v0 = fmaf(ph0[r], D0[r0 + r], v0);
+                        v1 = fmaf(ph1[r], D1[r0 + r], v1);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();                                 // jsh is rewritten by the next chunk
@@ -438,7 +443,7 @@ extern "C" int codlad_ic_decode(const codlad_decoder_weights *w, const float *z_
     CODLAD_REQUIRE(M > 0, "M must be positive");
     hipStream_t st = (hipStream_t)stream;
     const dim3 per_lane((M + 63) / 64), per_wave((M + EDGE_WAVES - 1) / EDGE_WAVES), block(256);
-    const int edge_grid = M < 12 * num_cu() ? M : 12 * num_cu();    // persistent waves, three per SIMD
+    const int edge_grid = M < 16 * num_cu() ? M : 16 * num_cu();    // persistent waves, four per SIMD
     const bool exact = dec_edge_variant() == 1;
     hipLaunchKernelGGL(dec_init_kernel, per_lane, block, 0, st, *w, z_q, cg_z, M, scratch);
     for (int blk = 0; blk < 4; ++blk) {

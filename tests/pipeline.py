@@ -51,7 +51,7 @@ class Config:
         return torch.randn(L, 3, generator=g, device=self.device)
 
     def run_units(self, unit_ids, decode_only=False):
-        """-> {unit id: (x0 [L,3], idx [L], xyz [n_atoms,3])} (device tensors).  decode_only: skip the
+        """-> {unit id: (x0 [L,3], idx [L], xyz [n_atoms,3], ic [L,13,3])} (device tensors).  decode_only: skip the
         sampler and decode `unit_latent` (VQ + IC decoder + ic_to_xyz only)."""
         unit_ids = sorted(unit_ids)
         # the structures this job needs, each once
@@ -86,7 +86,7 @@ class Config:
             a, b = int(off[k]), int(off[k + 1])
             ca = torch.from_numpy(prot["xyz_full"])[f][None].to(self.device)
             xyz = self.dec.ic_to_xyz(ca, ic[a:b].view(1, L, 13, 3), prot["info"])[0]
-            out[u] = (x0[a:b], idx[a:b], xyz)
+            out[u] = (x0[a:b], idx[a:b], xyz, ic[a:b])
         return out
 
 

@@ -20,21 +20,36 @@ pytestmark = pytest.mark.gpu
 PED_LENGTHS = list(synth.PED_LENGTHS)
 
 
-def check_decode_against_oracle(cfg, u, x0, idx, xyz):
+def check_decode_against_oracle(cfg, u, x0, idx, xyz, ic):
     """The decoder tail of unit u against the CPU oracle ON THE HIP PATH'S OWN LATENT (so a code flip at a Voronoi
-    boundary cannot enter): code indices bit-exact, coordinates RMSD <= 1e-4 A."""
+    boundary cannot enter): code indices bit-exact; internal coordinates within 2e-6 of an fp64 evaluation of the decoder
+    (the fp32 oracle itself sits at 1.4e-7 .. 1.8e-7, the kernels at 1.8e-7 .. 2.4e-7: tools/decode_precision_probe.py);
+    Cartesian coordinates RMSD <= 1e-4 A against the fp32 oracle - or, where ic -> xyz is ill-conditioned (untrained
+    K3 / K4 heads give near-collinear placement triplets at L = 155 .. 505: the reference's OWN fp32 result is then
+    2e-5 .. 1e-2 A from the fp64 one), no farther from the fp64 coordinates than three times the fp32 oracle is."""
     from oracle import vae_decode as odec
     p, f, _m = cfg.units[u]
     prot = cfg.proteins[p]
     L = prot["n_cg"]
     batch = synth.make_batch(prot, frame_ids=[f])
+    angle = cfg.vae_type != "N6"
     vsd = synth.vqvae_state_dict(cfg.vae_type, cfg.dataname, cfg.vae_seed)
     mean, std = synth.norm_stats(cfg.dataname, cfg.vae_type)
-    ridx, ic = odec.latent_decode(vsd, odec.denormalise(x0.cpu()[None], mean, std), batch, angle=cfg.vae_type != "N6")
-    ref = odec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4), ic.reshape(-1, L, 13, 3), prot["info"])
+    lat = odec.denormalise(x0.cpu()[None], mean, std)
+    ridx, ic32 = odec.latent_decode(vsd, lat, batch, angle=angle)
+    og = batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)
+    x32 = odec.ic_to_xyz(og, ic32.reshape(-1, L, 13, 3), prot["info"])[0]
     assert torch.equal(idx.cpu(), ridx.reshape(-1)), (u, L)
-    rmsd = float(((xyz.cpu() - ref[0]) ** 2).sum(-1).mean().sqrt())
-    assert rmsd < 1e-4, (u, L, rmsd)
+    vsd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in vsd.items()}
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    _i, ic64 = odec.latent_decode(vsd64, lat.double(), b64, angle=angle)
+    x64 = odec.ic_to_xyz(og.double(), ic64.reshape(-1, L, 13, 3), prot["info"])[0]
+    ic_err = float((ic.cpu().double() - ic64).abs().max() / ic64.abs().max())
+    assert ic_err < 2e-6, (u, L, ic_err)
+    rmsd = lambda a, b: float(((a.double() - b.double()) ** 2).sum(-1).mean().sqrt())  # noqa: E731
+    got = xyz.cpu()
+    assert rmsd(got, x32) < 1e-4 or rmsd(got, x64) < 3.0 * rmsd(x32, x64) + 2e-5, (u, L, rmsd(got, x32), rmsd(got, x64),
+                                                                                   rmsd(x32, x64))
 
 
 def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=(), decode_oracle_units=()):
@@ -52,7 +67,7 @@ def check_job(cfg, unit_ids, n_shards, shards_to_run, oracle_units=(), decode_or
             assert pipeline.same(whole[u], part[u]), (r, u)
     cb = cfg.dec.weights.codebook
     for u in unit_ids[:: max(1, len(unit_ids) // 50)]:
-        x0, idx, xyz = whole[u]
+        x0, idx, xyz, _ic = whole[u]
         assert bool(torch.isfinite(x0).all()) and bool(torch.isfinite(xyz).all())
         assert int(idx.min()) >= 0 and int(idx.max()) < cb.shape[0]
         idx2, zq2, _ = cfg.dec.vq(cb[idx], normalised=False)      # codes are fixed points of the lookup
