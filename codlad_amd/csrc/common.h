@@ -96,6 +96,8 @@ DEV void tile_store_row(const Tile &t, float *row, int h) {
 // chunk o, lanes 32-63: chunk o+1) and the 16 instructions of a 32-edge tile cover 16 contiguous KB (round 2; with
 // all 64 edges of a chunk together a tile was 32 runs of 512 B at a 1 KB stride: 3 % slower when an edge kernel is
 // launched back to back, no measurable difference inside the job).
+// In the split-fp16 modes the 16-byte slots of h_E0 and h_E hold fp16 halves instead of fp32 numbers (same bytes,
+// "pre-split edge state" below); E1 and the fp32-MFMA mode keep fp32.
 #define EDGE_BLOCK (64 * 128)
 #define EDGE_F4(e) (((e) & 31) + ((e) >> 5) * 1024)   // float4 index of edge e's first chunk; chunk stride 32
 // STREAM: the streaming (non-temporal) hint for a wave's own edge tile in the persistent kernels of large jobs - a tile
@@ -284,13 +286,87 @@ DEV void split_pair(SplitFrag &f, const Tile &in, int ks, int p, const GeluK &gk
     f.lo[2 * p] = ll.x; f.lo[2 * p + 1] = ll.y;
 }
 
-// One group = (k-step ks, out block bo): fragment prefetch for two groups ahead, a quarter of
-// the NEXT k-step's operand split (and GELU), TERMS MFMAs.  The sched_barrier closes the
-// scheduling region: inside it the compiler interleaves the VALU instructions with the four
-// MFMAs; across it nothing moves, which keeps register pressure bounded (left alone, hipcc hoists
-// loads and epilogue arithmetic across the whole 128-MFMA block and spills hundreds of registers).
-template <int TERMS, int KS0, int NKS, bool GELU_IN, bool TRANSPOSED = false>
+// Pre-split edge state (round 3).  The edge state h_E (and h_E0) of the split-fp16 modes is STORED as the fp16 halves the
+// contractions consume: the 16-byte slot that held four fp32 features now holds eight fp16 halves, laid out so that a
+// k-step's B-operand fragments are whole slots - for the eight features a lane half owns in k-step (b, s),
+//   f0 + {0,1,2,3} and f0 + 8 + {0,1,2,3},  f0 = 32 b + 16 s + 4 h,
+// the slot at chunk 8 b + 4 s + h holds their eight `hi` halves and the slot at chunk 8 b + 4 s + 2 + h their eight `lo`
+// halves.  Loaded with the same 16 instructions as before, registers 8 s .. 8 s + 3 of block b ARE the hi fragment and
+// 8 s + 4 .. 8 s + 7 the lo fragment: the layer-1 operand costs no vector instruction at all (before: convert + two
+// v_fma_mix per pair, 96 per tile and lane in the message kernel).  hi / lo are exactly what the on-the-fly split of the
+// fp32 value produces, so every contraction is bit-identical to round 2's; only a consumer that needs the VALUE (the edge
+// update's residual) sees hi + lo instead of the fp32 number, a difference of at most 2^-22 relative (2^-25 absolute
+// below 2^-3) - the representation error the contractions always had.
+DEV void presplit_frag(SplitFrag &f, const Tile &in, int ks) {
+    // four-register sub-vectors taken with constant shuffles and bit-cast as a whole: building the fragment element by
+    // element (u32x4{bits(v[r]), ...}) makes ROCm 7.2's clang narrow the tile's 16-byte loads to 4 bytes and splat
+    // element 0 (wrong code; the same pitfall as weight_load above)
+    const f32x16 &v = in.b[ks >> 1];
+    f32x4 a, b;
+    if (ks & 1) {
+        a = __builtin_shufflevector(v, v, 8, 9, 10, 11);
+        b = __builtin_shufflevector(v, v, 12, 13, 14, 15);
+    } else {
+        a = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+        b = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+    }
+    f.hi = __builtin_bit_cast(f16x8, a);
+    f.lo = __builtin_bit_cast(f16x8, b);
+}
+
+// fp32 chain tile -> stored form, in place (eight features of a k-step at a time)
+DEV void tile_presplit(Tile &t) {
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x2 hi[4], lo[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x2 x = {t.b[bo][8 * s + 2 * p], t.b[bo][8 * s + 2 * p + 1]};
+                hi[p] = __builtin_convertvector(x, f16x2);
+                lo[p] = split_lo_pair(hi[p], x);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                t.b[bo][8 * s + p] = __builtin_bit_cast(float, hi[p]);
+                t.b[bo][8 * s + 4 + p] = __builtin_bit_cast(float, lo[p]);
+            }
+        }
+}
+
+// stored form -> values (hi + lo in fp32), in place, fused with the edge update's residual set-up:
+// t = (hi + lo) * scale + row  (scale = 2^E of the block exponents, row = the pre-scaled bias b13)
+DEV void tile_unsplit_scale_add_row(Tile &t, float scale, const float *row, int h) {
+    const float4 *pr = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // the halves are taken out of whole four-register sub-vectors (see presplit_frag: bit-casting single
+            // elements of the tile to fp16 pairs is miscompiled by ROCm 7.2's clang)
+            SplitFrag f;
+            presplit_frag(f, t, 2 * bo + s);
+            const u32x4 hb = __builtin_bit_cast(u32x4, f.hi), lb = __builtin_bit_cast(u32x4, f.lo);
+            float val[8];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                // hi + lo in fp32 (exact: 22 bits), one v_fma_mix_f32 per element: f16 * 1.0 + f16
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(val[2 * p]) : "v"(hb[p]), "v"(lb[p]));
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(val[2 * p + 1]) : "v"(hb[p]), "v"(lb[p]));
+            }
+            const float4 ra = pr[8 * bo + 2 * (2 * s) + h], rb = pr[8 * bo + 2 * (2 * s + 1) + h];
+            t.b[bo][8 * s + 0] = fmaf(val[0], scale, ra.x); t.b[bo][8 * s + 1] = fmaf(val[1], scale, ra.y);
+            t.b[bo][8 * s + 2] = fmaf(val[2], scale, ra.z); t.b[bo][8 * s + 3] = fmaf(val[3], scale, ra.w);
+            t.b[bo][8 * s + 4] = fmaf(val[4], scale, rb.x); t.b[bo][8 * s + 5] = fmaf(val[5], scale, rb.y);
+            t.b[bo][8 * s + 6] = fmaf(val[6], scale, rb.z); t.b[bo][8 * s + 7] = fmaf(val[7], scale, rb.w);
+        }
+}
+
+// PRESPLIT: `in` holds the stored (pre-split) form of an edge tile; its fragments are taken as they are.
+template <int TERMS, int KS0, int NKS, bool GELU_IN, bool TRANSPOSED = false, bool PRESPLIT = false>
 DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk) {
+    static_assert(!(GELU_IN && PRESPLIT), "a stored tile is never an activation input");
     const u32x4 *w = wl + lane;
     constexpr int G0 = KS0 * 4, NG = NKS * 4;
     u32x4 ring[3][2];
@@ -300,8 +376,11 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const 
         ring[g][1] = w[((G0 + g) * 2 + 1) * 64];
     }
     SplitFrag x, xn;
+    if (PRESPLIT) presplit_frag(x, in, KS0);
+    else {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p, gk);
+        for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p, gk);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int ks = KS0 + (g >> 2), bo = g & 3;
@@ -309,17 +388,20 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const 
             ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];
             ring[(g + 2) % 3][1] = w[((G0 + g + 2) * 2 + 1) * 64];
         }
-        if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
+        if (!PRESPLIT && ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
         mfma_f16<TERMS, TRANSPOSED>(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
         __builtin_amdgcn_sched_barrier(0);
-        if (bo == 3) x = xn;
+        if (bo == 3) {
+            if (PRESPLIT) { if (ks + 1 < KS0 + NKS) presplit_frag(x, in, ks + 1); }
+            else x = xn;
+        }
     }
 }
 
 // acc += W @ act(in): GELU_IN applies GELU to `in` on the fly (see split_pair)
-template <int TERMS, bool GELU_IN, bool TRANSPOSED = false>
+template <int TERMS, bool GELU_IN, bool TRANSPOSED = false, bool PRESPLIT = false>
 DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk) {
-    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED>(acc, in, wl, lane, gk);
+    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED, PRESPLIT>(acc, in, wl, lane, gk);
 }
 
 // The same k-step with the weight fragments fetched from global memory (L2-resident) through a
@@ -331,7 +413,7 @@ DEV u32x4 weight_frag_load(__amdgpu_buffer_rsrc_t rsrc, int lane, int frag_index
 // DEPTH = groups in flight.  start() issues the first DEPTH-1 groups' fragment loads and can be
 // called long before run(), so that the L2 latency of a streamed block is paid while the wave does
 // something else (other loads, the LDS-resident part of the same contraction).
-template <int TERMS, int KS0, int NKS, bool GELU_IN, int DEPTH = 4>
+template <int TERMS, int KS0, int NKS, bool GELU_IN, int DEPTH = 4, bool PRESPLIT = false>
 struct StreamedGemm {
     static constexpr int G0 = KS0 * 4, NG = NKS * 4;
     static_assert((DEPTH & (DEPTH - 1)) == 0 && DEPTH <= NG, "ring depth: power of two, at most the group count");
@@ -350,8 +432,11 @@ struct StreamedGemm {
 
     DEV void run(Tile &acc, const Tile &in, int lane, const GeluK &gk) {
         SplitFrag x, xn;
+        if (PRESPLIT) presplit_frag(x, in, KS0);
+        else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p, gk);
+            for (int p = 0; p < 4; ++p) split_pair<GELU_IN>(x, in, KS0, p, gk);
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int ks = KS0 + (g >> 2), bo = g & 3;
@@ -359,17 +444,20 @@ struct StreamedGemm {
                 ring[(g + DEPTH - 1) & (DEPTH - 1)][0] = weight_frag_load(rsrc, lane, (G0 + g + DEPTH - 1) * 2 + 0);
                 ring[(g + DEPTH - 1) & (DEPTH - 1)][1] = weight_frag_load(rsrc, lane, (G0 + g + DEPTH - 1) * 2 + 1);
             }
-            if (ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
+            if (!PRESPLIT && ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
             mfma_f16<TERMS>(acc.b[bo], as_f16x8(ring[g & (DEPTH - 1)][0]), as_f16x8(ring[g & (DEPTH - 1)][1]), x);
             __builtin_amdgcn_sched_barrier(0);
-            if (bo == 3) x = xn;
+            if (bo == 3) {
+                if (PRESPLIT) { if (ks + 1 < KS0 + NKS) presplit_frag(x, in, ks + 1); }
+                else x = xn;
+            }
         }
     }
 };
 
-template <int TERMS, int KS0, int NKS, bool GELU_IN>
+template <int TERMS, int KS0, int NKS, bool GELU_IN, bool PRESPLIT = false>
 DEV void gemm_h_glb(Tile &acc, const Tile &in, const void *Wpacked, int lane, const GeluK &gk) {
-    StreamedGemm<TERMS, KS0, NKS, GELU_IN, 4> g;
+    StreamedGemm<TERMS, KS0, NKS, GELU_IN, 4, PRESPLIT> g;
     g.start(Wpacked, lane);
     g.run(acc, in, lane, gk);
 }

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256, 1) void layer0_kernel(Layer0Args a) {
         for (int which = 0; which < 2; ++which) {
             Tile acc;
             tile_zero(acc);
-            if constexpr (TERMS != 0) gemm_h_glb<TERMS, 0, 8, false>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane, gelu_consts(0));
+            if constexpr (TERMS != 0) gemm_h_glb<TERMS, 0, 8, false, true>(acc, x, which ? a.Wh_upd : a.Wh_msg, lane, gelu_consts(0));   // h_E0 as stored (pre-split)
             else gemm128(acc, x, which ? a.W_upd : a.W_msg, lane);
             if (valid) tile_store_edge(acc, a.E1 + ((size_t)which * a.n_snodes + m) * EDGE_BLOCK, col, h);
         }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_kernel_h(EdgeArgs
 #pragma unroll
             for (int bo = 0; bo < 4; ++bo) acc.b[bo] += x.b[bo];
         } else {
-            gemm128_h_lds<TERMS, false>(acc, x, w1, lane, a.gelu_a);      // layer 1
+            gemm128_h_lds<TERMS, false, false, true>(acc, x, w1, lane, a.gelu_a);      // layer 1, h_E tile as stored (pre-split)
         }
         if (first_half && next_node) {                   // next node's neighbour list and P row
             nsrc = __builtin_amdgcn_readfirstlane(ninfo.x);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_tile_kernel_h(Edg
         const int colc = valid ? col : 0;
         const int j = a.E_idx[(size_t)src * 64 + colc];
         Tile x, acc, t2;
-        StreamedGemm<TERMS, UPD_W1_KS, 8 - UPD_W1_KS, false, 8> tail1;
+        StreamedGemm<TERMS, UPD_W1_KS, 8 - UPD_W1_KS, false, 8, true> tail1;
         if (!HOISTED) tail1.start(a.W1h, lane);
         // the constants never change, so the compiler would read them once, before the node
         // loop, into ~300 registers and spill those; an opaque zero offset keeps the reads here
@@ -75,16 +75,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_tile_kernel_h(Edg
         if (HOISTED) {
             tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
         } else {
-            gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps
+            gemm_h_lds<TERMS, 0, UPD_W1_KS, false, false, true>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps
             tail1.run(acc, x, lane, a.gelu_a);                                    // layer 1, streamed k-steps
         }
         tile_load_row(t2, c_b2, h);
         gemm128_h_lds<TERMS, true>(t2, acc, w2, lane, a.gelu_a);   // layer 2 on GELU(layer 1)
         // layer 3 accumulates onto (h_E + b13) * 2^E: the input tile stays in registers for the
         // residual instead of being fetched from HBM a second time (c_b3 holds b13 * 2^E)
-        tile_scale_add_row(x, a.res_scale, c_b3, h);
+        tile_unsplit_scale_add_row(x, a.res_scale, c_b3, h);       // x arrives pre-split: its value is hi + lo
         gemm128_h_lds<TERMS, true>(x, t2, w3, lane, a.gelu_b);     // layer 3 on GELU(layer 2)
         tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);
+        tile_presplit(x);
         if (valid) tile_store_edge(x, out_rows, col, h);
     };
     // this node's P row: one coalesced 512-byte read, staged in the wave's own LDS slot
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_tile_kernel_h(Edg
 #pragma unroll
                 for (int bo = 0; bo < 4; ++bo) acc.b[bo] += x.b[bo];
             } else {
-                gemm128_h_lds<TERMS, false>(acc, x, w1, lane, a.gelu_a);      // layer 1
+                gemm128_h_lds<TERMS, false, false, true>(acc, x, w1, lane, a.gelu_a);      // layer 1 (pre-split h_E tile)
             }
             const int nsrc = __builtin_amdgcn_readfirstlane(ninfo.x), nbase = __builtin_amdgcn_readfirstlane(ninfo.y);
             const int nK = __builtin_amdgcn_readfirstlane(ninfo.z);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void msg_tile_kernel_h(Edg
 #pragma unroll
             for (int bo = 0; bo < 4; ++bo) acc.b[bo] += x.b[bo];
         } else {
-            gemm128_h_lds<TERMS, false>(acc, x, w1, lane, a.gelu_a);      // layer 1
+            gemm128_h_lds<TERMS, false, false, true>(acc, x, w1, lane, a.gelu_a);      // layer 1 (pre-split h_E tile)
         }
         if (first_half && next_node) {                   // next node's neighbour list and P row
             nsrc = __builtin_amdgcn_readfirstlane(ninfo.x);

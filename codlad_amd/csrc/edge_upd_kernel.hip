@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
             const int colc = half ? colB : colA, col = 32 * half + c;
             const int j = half ? jB : jA;
             Tile x, acc, t2;
-            StreamedGemm<TERMS, UPD_W1_KS, 8 - UPD_W1_KS, false, 8> tail1;
+            StreamedGemm<TERMS, UPD_W1_KS, 8 - UPD_W1_KS, false, 8, true> tail1;
             if (!HOISTED) tail1.start(a.W1h, lane);
             // the constants never change, so the compiler would read them once, before the node
             // loop, into ~300 registers and spill those; an opaque zero offset keeps the reads here
@@ -77,20 +77,28 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void upd_kernel_h(EdgeArgs
             const float *c_modA = c_b2 + 2 * HD, *c_modB = c_b2 + 3 * HD;
             tile_load_row(acc, a.Q + (size_t)(base + j) * HD, h);
             tile_add_row(acc, Pslot, h);
-            tile_load_edge<!HOISTED>(x, rows, colc, h);                          // layer-1 operand and residual
+            if (!HOISTED) tile_load_edge<true>(x, rows, colc, h);                // layer-1 operand and residual
             if (HOISTED) {
                 tile_add_edge(acc, a.E1 + (size_t)src * EDGE_BLOCK, colc, h);
+                // the tile itself (h_E0, shared by the ensemble members: default cache policy) is only the residual here:
+                // requested after the hoisted term has been added, it travels under layer 2.  (Requested first, as the
+                // non-hoisted variant must, hipcc serialised the sixteen E1 loads behind it, one s_waitcnt vmcnt(0) each:
+                // +25 % on this launch.)
+                __builtin_amdgcn_sched_barrier(0);
+                tile_load_edge<false>(x, rows, colc, h);
             } else {
-                gemm_h_lds<TERMS, 0, UPD_W1_KS, false>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps
+                gemm_h_lds<TERMS, 0, UPD_W1_KS, false, false, true>(acc, x, w1, lane, a.gelu_a);   // layer 1, resident k-steps
                 tail1.run(acc, x, lane, a.gelu_a);                                    // layer 1, streamed k-steps
             }
             tile_load_row(t2, c_b2, h);
             gemm128_h_lds<TERMS, true>(t2, acc, w2, lane, a.gelu_a);   // layer 2 on GELU(layer 1)
             // layer 3 accumulates onto (h_E + b13) * 2^E: the input tile stays in registers for the
             // residual instead of being fetched from HBM a second time (c_b3 holds b13 * 2^E)
-            tile_scale_add_row(x, a.res_scale, c_b3, h);
+            // (x arrives in the stored, pre-split form: its value is hi + lo)
+            tile_unsplit_scale_add_row(x, a.res_scale, c_b3, h);
             gemm128_h_lds<TERMS, true>(x, t2, w3, lane, a.gelu_b);     // layer 3 on GELU(layer 2)
             tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);
+            tile_presplit(x);                                          // stored as the halves the next contraction reads
             if (valid) tile_store_edge<true>(x, out_rows, col, h);
         }
     }

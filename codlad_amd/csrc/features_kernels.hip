@@ -222,9 +222,31 @@ __global__ __launch_bounds__(256) void features_kernel(codlad_denoiser_weights w
         }
         // edge block (common.h, EDGE_BLOCK): [2 halves][32 chunks][32 edges][4 floats]
         float4 *out = reinterpret_cast<float4 *>(hE0 + (size_t)m * (64 * HD)) + (k >> 5) * 1024 + (8 * part) * 32 + (k & 31);
+        if (w.precision == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            out[e * 32] = make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3]);
+            for (int e = 0; e < 8; ++e)
+                out[e * 32] = make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3]);
+        } else {
+            // split-fp16 modes: the stored form the contractions read (common.h, "pre-split edge state"): for s, hh the
+            // eight features 16 s + 4 hh + {0..3} and 16 s + 8 + 4 hh + {0..3} of this 32-feature block go as eight `hi`
+            // halves to chunk 4 s + hh and as eight `lo` halves to chunk 4 s + 2 + hh
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int f = 16 * s + 8 * (p >> 1) + 4 * hh + 2 * (p & 1);
+                        const f32x2 x = {acc[f], acc[f + 1]};
+                        const f16x2 hv = __builtin_convertvector(x, f16x2);
+                        hi[p] = __builtin_bit_cast(unsigned, hv);
+                        lo[p] = __builtin_bit_cast(unsigned, split_lo_pair(hv, x));
+                    }
+                    reinterpret_cast<uint4 *>(out)[(4 * s + hh) * 32] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                    reinterpret_cast<uint4 *>(out)[(4 * s + 2 + hh) * 32] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                }
+        }
         if (part == 0) E_idx[(size_t)m * 64 + k] = nb[k];
     }
 }

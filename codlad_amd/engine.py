@@ -25,11 +25,23 @@ def _require_cuda(t, what):
         raise RuntimeError(f"{what} must live on the GPU: this path has no CPU implementation")
 
 
-def edge_rows(blocks):
+def edge_rows(blocks, split=False):
     """Edge state as the kernels keep it in HBM ([..., 2 halves, 32 chunks, 32 edges, 4], include/codlad_hip.h)
-    -> [..., 64 edges, 128 features]."""
+    -> [..., 64 edges, 128 features].  split: the blocks are h_E0 / h_E of a split-fp16 contraction mode, whose 16-byte
+    slots hold fp16 halves (slot 8 b + 4 s + h: the `hi` halves of features 32 b + 16 s + 4 h + {0..3, 8..11}, slot
+    8 b + 4 s + 2 + h their `lo` halves); the values returned are hi + lo."""
     lead = blocks.shape[:-4]
-    return blocks.permute(*range(len(lead)), -4, -2, -3, -1).reshape(*lead, 64, -1)
+    if not split:
+        return blocks.permute(*range(len(lead)), -4, -2, -3, -1).reshape(*lead, 64, -1)
+    hv = blocks.contiguous().view(torch.float16).view(*lead, 2, 4, 2, 2, 2, 32, 8)      # half, b, s, hi|lo, h, edge, 8
+    val = hv[..., 0, :, :, :].float() + hv[..., 1, :, :, :].float()                       # [.., half, b, s, h, edge, 8]
+    n = len(lead)
+    val = val.permute(*range(n), n, n + 4, n + 1, n + 2, n + 3, n + 5)                    # [.., half, edge, b, s, h, 8]
+    out = torch.empty(*lead, 2, 32, 4, 2, 16, dtype=torch.float32, device=blocks.device)  # feature = 32 b + 16 s + (0..15)
+    for h in range(2):
+        out[..., 4 * h:4 * h + 4] = val[..., h, 0:4]
+        out[..., 8 + 4 * h:8 + 4 * h + 4] = val[..., h, 4:8]
+    return out.reshape(*lead, 64, 128)
 
 
 class Structures:
@@ -146,6 +158,11 @@ class Denoiser:
             _lib.check(rc, "codlad_layer0_edge_terms")
         st.features_tag = self.features_tag()
         return st
+
+    @property
+    def split_edge_state(self):
+        """True when h_E0 / h_E are kept as fp16 hi / lo halves (the split-fp16 modes), see edge_rows."""
+        return self.weights.precision != "f32"
 
     def features_tag(self):
         """What the hoisted layer-0 terms E1 depend on besides the structure: in the split-fp16 modes they carry

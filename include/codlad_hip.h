@@ -146,7 +146,14 @@ typedef struct {
  * other and "chunk-major" within a half: [2 halves][32 chunks of 4 features][32 edges][4 floats] (feature f
  * of edge e at float 4096*(e/32) + 128*(f/4) + 4*(e%32) + f%4), so that the 16 bytes neighbouring lanes
  * (edges) move per instruction are neighbours in memory and a 32-edge tile is 16 contiguous KB; slots of
- * edges e >= K are never written.  E1 and the workspace's hE use the same block layout. */
+ * edges e >= K are never written.  E1 and the workspace's hE use the same block layout.
+ * Contents of a 16-byte slot: four fp32 features in the fp32-MFMA mode (precision 0) and for E1 in every mode; in the
+ * split-fp16 modes (precision 1, 2) h_E0 and hE are stored as the fp16 halves the contractions consume ("pre-split", same
+ * bytes): for b = 0..3, s = 0..1, h = 0..1 the eight features 32 b + 16 s + 4 h + {0,1,2,3, 8,9,10,11} of an edge keep
+ * their eight `hi` halves (fp16 of the value, round to nearest) in chunk slot 8 b + 4 s + h and their eight `lo` halves
+ * (fp16 of value - hi) in chunk slot 8 b + 4 s + 2 + h; the value is hi + lo (22 significant bits).  The edge state is
+ * internal to a (structures, workspace) pair: a caller never reads it, and one that changes w->precision must call
+ * codlad_features_prepass again (the Python layer does). */
 int codlad_features_prepass(const codlad_denoiser_weights *w, const float *cg_xyz,
                             const int32_t *snode_info, int n_snodes, int max_len,
                             int32_t *E_idx, float *h_E0, void *stream);

@@ -123,7 +123,7 @@ def test_features_prepass(den, sd, name):
     # compare edge features edge by edge: bring the oracle's rows into this kernel's neighbour order
     perm = (got_idx[..., :, None] == E_idx[..., None, :]).float().argmax(-1)   # [B,L,K]
     hE0 = torch.gather(hE0, 2, perm[..., None].expand(-1, -1, -1, 128))
-    got = engine.edge_rows(st.h_E0).cpu().view(B, L, 64, 128)[:, :, :K]
+    got = engine.edge_rows(st.h_E0, split=den.split_edge_state).cpu().view(B, L, 64, 128)[:, :, :K]
     # The quaternion features are ill-conditioned by construction in the reference: for the self
     # edge (and any neighbour with a parallel frame) R = O_i^T O_j ~ I and the magnitudes
     # 0.5*sqrt(|1 + Rxx - Ryy - Rzz|) are the square root of rounding noise (~1e-4) with a noise
@@ -240,7 +240,7 @@ def test_hoisted_layer0_edge_terms(den, sd):
     assert st.E1 is not None and tuple(engine.edge_rows(st.E1).shape) == (2, 127, 64, 128)
     K = torch.tensor([40] * 40 + [64] * 87, device=DEV)
     valid = (torch.arange(64, device=DEV)[None, :] < K[:, None])
-    hE = engine.edge_rows(st.h_E0).double()
+    hE = engine.edge_rows(st.h_E0, split=den.split_edge_state).double()
     ex = den.weights.exponents["enc0"]
     for which, name in enumerate(["W1", "W11"]):
         W = sd[f"encoder_layers.0.{name}.weight"][:, 128:256].to(DEV).double()

@@ -206,6 +206,24 @@ def test_edge_block_layout_helper():
     for e, f in ((13, 77), (45, 6)):
         assert float(flat[1, 4096 * (e // 32) + 128 * (f // 4) + 4 * (e % 32) + f % 4]) == float(rows[1, e, f])
     assert tuple(edge_rows(torch.zeros(2, 5, 2, 32, 32, 4)).shape) == (2, 5, 64, 128)
+    # the stored form of the split-fp16 modes (csrc/common.h "pre-split edge state"): build it from values the way
+    # tile_presplit does and read it back
+    vals = torch.randn(3, 64, 128) * 4
+    hi = vals.to(torch.float16)
+    lo = (vals - hi.float()).to(torch.float16)
+    stored = torch.zeros(3, 2, 32, 32, 8, dtype=torch.float16)
+    for b in range(4):
+        for s_ in range(2):
+            for h in range(2):
+                f0 = 32 * b + 16 * s_ + 4 * h
+                feats = list(range(f0, f0 + 4)) + list(range(f0 + 8, f0 + 12))
+                for half in range(2):
+                    e = slice(32 * half, 32 * half + 32)
+                    stored[:, half, 8 * b + 4 * s_ + h] = hi[:, e][:, :, feats]
+                    stored[:, half, 8 * b + 4 * s_ + 2 + h] = lo[:, e][:, :, feats]
+    back = edge_rows(stored.view(torch.float32).view(3, 2, 32, 32, 4), split=True)
+    assert torch.equal(back, hi.float() + lo.float())
+    assert float((back - vals).abs().max()) < 4 * 2.0 ** -22 * 16
 
 
 def test_split_pack_refuses_weights_outside_fp16_range():
