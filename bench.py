@@ -149,13 +149,14 @@ class Workload:
         x0 = self.latent if self.decode_only else self.den.sample(self.job, self.x_T, self.noise, self.tables)
         idx, zq, _lat = self.dec.vq(x0)
         ic = self.dec.ic_decode(zq, self.cg_z, self.cg_xyz, csr=self.csr)
-        out = []
+        groups = []
         for start, count, prot, ca in self.groups:
             L = prot["n_cg"]
             a = int(self.job.sample_off[start])
             b = int(self.job.sample_off[start + count])
-            out.append(self.dec.ic_to_xyz(ca, ic[a:b].view(count, L, 13, 3), prot["info"]))
-        return out, idx
+            groups.append((ca, ic[a:b].view(count, L, 13, 3), prot["info"]))
+        # every protein's placements in one launch (one launch per protein is latency-bound: 20 us each)
+        return self.dec.ic_to_xyz_groups(groups, reuse=True), idx
 
     def timed(self, fn, n=1):
         """Average wall time of fn() in seconds by HIP events on the stream the kernels are enqueued on."""

@@ -74,6 +74,11 @@ class TpConvArgs(C.Structure):
                 ("fc3_b", P), ("depth", C.c_int32), ("out", P), ("accumulate", C.c_int32), ("group", C.c_int32)]
 
 
+class XyzGroup(C.Structure):
+    _fields_ = [("ca_full", P), ("ic", P), ("orders", P), ("slot_to_out", P), ("xyz_out", P),
+                ("B", C.c_int32), ("L", C.c_int32), ("n_atoms", C.c_int32), ("first_row", C.c_int32)]
+
+
 class MetricInputs(C.Structure):
     _fields_ = [("xyz_recon", P), ("xyz", P), ("n_atoms", C.c_int64),
                 ("edge_list", P), ("n_edges", C.c_int64), ("clash_list", P), ("n_clash", C.c_int64),
@@ -108,6 +113,7 @@ _SIGS = {
     "codlad_ic_decode": (C.c_int, [C.POINTER(DecoderWeights), P, P, P, P, P, C.c_int, P, P, P]),
     "codlad_cg_graph": (C.c_int, [P, P, C.c_int, C.c_float, P, P, P, P]),
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
+    "codlad_ic_to_xyz_groups": (C.c_int, [P, C.c_int, C.c_int, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, C.c_int, P]),
     "codlad_tp_conv": (C.c_int, [C.POINTER(TpConvArgs), P]),
@@ -141,7 +147,7 @@ def lib():
     return _lib
 
 
-OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_LOOP_GRAPH_MAX_NODES, OPT_DEC_EDGE_VARIANT = 0, 1, 2, 3   # CODLAD_OPT_* of include/codlad_hip.h
+OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT = 0, 1, 3   # CODLAD_OPT_* of include/codlad_hip.h
 
 
 def set_option(option, value):

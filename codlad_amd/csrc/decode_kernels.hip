@@ -155,17 +155,11 @@ DEV V3 place_atom(const float *ic3, V3 atom1, V3 atom2, V3 atom3) {
     return v3(atom1.x + d.x, atom1.y + d.y, atom1.z + d.z);
 }
 
-__global__ __launch_bounds__(128) void ic_to_xyz_kernel(const float *ca_full, const float *ic,
-                                                       const int32_t *orders,
-                                                       const int32_t *slot_to_out, int B, int L,
-                                                       int n_atoms, float *xyz_out) {
-    // the 14 atoms of the residue in LDS, one column per thread: the side-chain placements pick their three reference
-    // atoms by index (orders), and a register array indexed at run time would live in scratch memory
-    __shared__ float ax[14][128], ay[14][128], az[14][128];
-    const int tid = threadIdx.x;
-    const int t = blockIdx.x * blockDim.x + tid;
-    if (t >= B * L) return;
-    const int b = t / L, r = t - b * L;
+// one (frame, residue): the 14 atoms of the residue in LDS, one column per thread - the side-chain placements pick their
+// three reference atoms by index (orders), and a register array indexed at run time would live in scratch memory
+DEV void ic_to_xyz_row(const float *ca_full, const float *ic, const int32_t *orders, const int32_t *slot_to_out, int b,
+                       int r, int L, int n_atoms, float *xyz_out, float (*ax)[128], float (*ay)[128], float (*az)[128],
+                       int tid) {
     const float *ca = ca_full + ((size_t)b * (L + 2) + r) * 3;  // residue r-1 (flanking) .. r+1
     const V3 prv = v3(ca[0], ca[1], ca[2]), mid = v3(ca[3], ca[4], ca[5]), nxt = v3(ca[6], ca[7], ca[8]);
     const float *icr = ic + ((size_t)b * L + r) * 39;
@@ -188,6 +182,35 @@ __global__ __launch_bounds__(128) void ic_to_xyz_kernel(const float *ca_full, co
     }
 }
 
+__global__ __launch_bounds__(128) void ic_to_xyz_kernel(const float *ca_full, const float *ic,
+                                                       const int32_t *orders,
+                                                       const int32_t *slot_to_out, int B, int L,
+                                                       int n_atoms, float *xyz_out) {
+    __shared__ float ax[14][128], ay[14][128], az[14][128];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + tid;
+    if (t >= B * L) return;
+    const int b = t / L, r = t - b * L;
+    ic_to_xyz_row(ca_full, ic, orders, slot_to_out, b, r, L, n_atoms, xyz_out, ax, ay, az, tid);
+}
+
+// several proteins (different L, atom tables) in ONE launch: thread t belongs to the group g with
+// first_row[g] <= t < first_row[g + 1]
+__global__ __launch_bounds__(128) void ic_to_xyz_groups_kernel(const codlad_xyz_group *groups, int n_groups, int total) {
+    __shared__ float ax[14][128], ay[14][128], az[14][128];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + tid;
+    if (t >= total) return;
+    int lo = 0, hi = n_groups - 1;                       // last group whose first_row <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (groups[mid].first_row <= t) lo = mid; else hi = mid - 1;
+    }
+    const codlad_xyz_group g = groups[lo];
+    const int k = t - g.first_row, b = k / g.L, r = k - b * g.L;
+    ic_to_xyz_row(g.ca_full, g.ic, g.orders, g.slot_to_out, b, r, g.L, g.n_atoms, g.xyz_out, ax, ay, az, tid);
+}
+
 extern "C" int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *orders,
                                 const int32_t *slot_to_out, int B, int L, int n_atoms,
                                 float *xyz_out, void *stream) {
@@ -196,4 +219,11 @@ extern "C" int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int
     hipLaunchKernelGGL(ic_to_xyz_kernel, dim3((B * L + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                        ca_full, ic, orders, slot_to_out, B, L, n_atoms, xyz_out);
     return codlad_check_launch("codlad_ic_to_xyz");
+}
+
+extern "C" int codlad_ic_to_xyz_groups(const codlad_xyz_group *groups_dev, int n_groups, int total_rows, void *stream) {
+    CODLAD_REQUIRE(groups_dev && n_groups > 0 && total_rows > 0, "bad arguments");
+    hipLaunchKernelGGL(ic_to_xyz_groups_kernel, dim3((total_rows + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       groups_dev, n_groups, total_rows);
+    return codlad_check_launch("codlad_ic_to_xyz_groups");
 }

@@ -415,6 +415,40 @@ class Decoder:
         return out
 
 
+    def ic_to_xyz_groups(self, groups, reuse=False):
+        """groups: [(ca_full [B,L+2,3], ic [B,L,13,3], info)] of several proteins -> [xyz [B,n_atoms,3]] in ONE launch
+        (codlad_ic_to_xyz_groups).  reuse: keep the descriptor table AND the output tensors of the previous call when the
+        inputs sit at the same addresses (a job that is run again and again: the results of the earlier call are
+        overwritten); default: a fresh table and fresh outputs per call (one small host-to-device copy)."""
+        key = tuple((ca.data_ptr(), ic.data_ptr(), id(info[0]), tuple(ic.shape)) for ca, ic, info in groups)
+        cache = getattr(self, "_xyz_groups", None) if reuse else None
+        if cache is None or cache[0] != key:
+            desc = (_lib.XyzGroup * len(groups))()
+            outs, keep, row = [], [], 0
+            for g, (ca, ic, info) in enumerate(groups):
+                _require_cuda(ic, "ic")
+                B, L = ic.shape[0], ic.shape[1]
+                orders, s2o, n_atoms = info_tables(info, L, self.device)
+                ca_d, ic_d = ca.to(self.device).contiguous().float(), ic.contiguous().float()
+                assert ic_d.data_ptr() == ic.data_ptr() and ca_d.shape == (B, L + 2, 3)
+                out = torch.empty(B, n_atoms, 3, dtype=torch.float32, device=self.device)
+                d = desc[g]
+                d.ca_full, d.ic, d.orders, d.slot_to_out, d.xyz_out = (ca_d.data_ptr(), ic_d.data_ptr(), orders.data_ptr(),
+                                                                       s2o.data_ptr(), out.data_ptr())
+                d.B, d.L, d.n_atoms, d.first_row = B, L, n_atoms, row
+                row += B * L
+                outs.append(out)
+                keep += [ca_d, ic_d, orders, s2o]
+            table = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(self.device)
+            cache = (key, table, outs, keep, row)
+            if reuse:
+                self._xyz_groups = cache
+        _key, table, outs, _keep, rows = cache
+        rc = self.lib.codlad_ic_to_xyz_groups(_lib.ptr(table), len(groups), rows, _lib.stream_ptr(self.device))
+        _lib.check(rc, "codlad_ic_to_xyz_groups")
+        return outs
+
+
 _INFO_CACHE = {}
 
 

@@ -335,19 +335,29 @@ int codlad_ic_to_xyz(const float *ca_full, const float *ic, const int32_t *order
                      const int32_t *slot_to_out, int B, int L, int n_atoms, float *xyz_out,
                      void *stream);
 
+/* The same for several proteins (each its own L, atom tables and output) in ONE launch: `groups` is a DEVICE array of
+ * n_groups descriptors, first_row = the number of (frame, residue) rows of the groups before it (ascending from 0),
+ * total_rows = the sum of B * L.  A job of many short proteins otherwise pays one latency-bound launch per protein. */
+typedef struct {
+    const float *ca_full, *ic;
+    const int32_t *orders, *slot_to_out;
+    float *xyz_out;
+    int32_t B, L, n_atoms, first_row;
+} codlad_xyz_group;
+int codlad_ic_to_xyz_groups(const codlad_xyz_group *groups, int n_groups, int total_rows, void *stream);
+
 /* Tuning switches (speed only: every setting computes the same values).  Defaults suit MI355X; the environment
  * variable of the same name (CODLAD_ prefix, upper case) sets the initial value.
  *   CODLAD_OPT_NODEQ_MAX_TILES   jobs of up to this many 32-node tiles run the node update on the small-job
  *                                "quarter" kernel (one tile per 4-wave workgroup), larger ones on the streaming one
  *   CODLAD_OPT_EDGE_TILE_MAX_NODES  jobs of up to this many nodes deal the edge kernels' work out per 32-edge
  *                                tile instead of per node (twice the waves for the same work)
- *   CODLAD_OPT_LOOP_GRAPH_MAX_NODES  reserved
+ *   (slot 2 is unused: the round-2 header reserved it for a captured / persistent step loop that was never built)
  *   CODLAD_OPT_DEC_EDGE_VARIANT  IC decoder messages: 0 = one sine / cosine + recurrence, 15 -> 40 filter on the f16 matrix
  *                                pipe (split fp16, fp32-equivalent); 1 = 15 library sines and fp32 FMAs (round-2 kernel).
  *                                NOT bit-identical to each other (both within the decoder's parity tolerance) */
 #define CODLAD_OPT_NODEQ_MAX_TILES 0
 #define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
-#define CODLAD_OPT_LOOP_GRAPH_MAX_NODES 2
 #define CODLAD_OPT_DEC_EDGE_VARIANT 3
 #define CODLAD_N_OPTIONS 8
 int codlad_set_option(int option, int value);

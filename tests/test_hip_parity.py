@@ -432,6 +432,22 @@ def test_ic_decode_message_kernel_variants(name):
                                              batch["CG_nbr_list"]))          # deterministic
 
 
+def test_ic_to_xyz_groups_equals_one_launch_per_protein():
+    """codlad_ic_to_xyz_groups: several proteins (different lengths and atom tables) in one launch give exactly the
+    coordinates of one codlad_ic_to_xyz launch per protein."""
+    dec = Decoder(synth.vqvae_state_dict("N6", "PED", cases.VAE_SEED), DEV)
+    groups, want = [], []
+    for L, B, seed in ((46, 3, 1), (129, 1, 2), (5, 2, 3), (87, 4, 4)):
+        prot = synth.make_protein(L, 70 + seed, n_frames=B)
+        ca = torch.from_numpy(prot["xyz_full"]).float().to(DEV)
+        ic = (synth.gaussian((B, L, 13, 3), 80 + seed) * torch.tensor([0.1, 0.5, 1.0]) + torch.tensor([1.5, 1.9, 0.0])).to(DEV)
+        groups.append((ca, ic, prot["info"]))
+        want.append(dec.ic_to_xyz(ca, ic, prot["info"]))
+    for reuse in (False, True, True):
+        got = dec.ic_to_xyz_groups(groups, reuse=reuse)
+        assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want))
+
+
 def test_cg_graph_on_device_equals_reference_neighbour_list():
     """codlad_cg_graph == get_neighbor_list + make_directed + receiver-sorted scatter order."""
     dec = Decoder(synth.vqvae_state_dict("N6", "PED", cases.VAE_SEED), DEV)

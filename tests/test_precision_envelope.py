@@ -77,6 +77,38 @@ def test_fp16_range_overflow_is_an_error_not_a_number(precision):
     assert bool(torch.isfinite(out32).all())
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16x4"])
+@pytest.mark.parametrize("site", ["edge_state", "node_state", "decoder_node_state"])
+def test_overflow_is_reported_wherever_it_first_appears(precision, site):
+    """The sentinel must not depend on WHERE a value first leaves the fp16 range (the edge kernels are compiled with
+    -fno-honor-nans, under which a compiler is free to assume NaN away: a change that swallowed one of these would pass
+    the features-only test above).  edge_state: encoder layer 0's gate3 / scale3 / shift3 heads x 1e6 - h_E overflows
+    when the edge update stores it as fp16 halves; node_state: x_in x 1e7 - h_V overflows when the first node kernel
+    splits it for the P / Q projections; decoder_node_state: decoder layer 1's adaLN heads x 1e7 - h_V overflows in
+    the middle of the decoder.  In each case the f32 mode runs the same weights to a finite result."""
+    L, B, seed = cases.ENVELOPE_GEOMETRY
+    prot, batch, x, t, mask = cases.denoiser_inputs(L, B, seed)
+    sd = synth.denoiser_state_dict(cases.WEIGHT_SEED)
+    if site == "edge_state":
+        for k in ("weight", "bias"):
+            w = sd[f"encoder_layers.0.adaLN_modulation.1.{k}"].clone()
+            w[6 * 128:] *= 1e6
+            sd[f"encoder_layers.0.adaLN_modulation.1.{k}"] = w
+    elif site == "node_state":
+        sd["x_in.weight"] = sd["x_in.weight"] * 1e7
+    else:
+        for k in ("weight", "bias"):
+            sd[f"decoder_layers.1.adaLN_modulation.1.{k}"] = sd[f"decoder_layers.1.adaLN_modulation.1.{k}"] * 1e7
+    xd = x.reshape(-1, 3).to(DEV)
+    den = Denoiser(sd, DEV, precision=precision)
+    job = job_of(den, prot, B)
+    with pytest.raises(RuntimeError, match="not finite"):
+        den.forward(job, xd, 500)
+    den.weights.set_precision("f32")
+    job.status.zero_()
+    assert bool(torch.isfinite(den.forward(job, xd, 500)).all())
+
+
 def test_weights_beyond_fp16_range_are_refused_at_pack_time():
     """A weight matrix with no accurate fp16 hi/lo split (an element that no block exponent brings into range without
     costing the rest its precision) is refused when packed, instead of storing inf or garbage."""

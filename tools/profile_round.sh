@@ -30,3 +30,10 @@ WRITE_SIZE
 SETS
 cat $OUT/pmc*.txt > $OUT/pmc_summary.txt
 rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
+# decoder tail (cfg 5): kernel stats, variant A/B, precision of the two message kernels against fp64
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace5 --output-format csv -- python3 bench.py --config cfg5 --no-cpu-baseline --steps 4 --warmup 1 > $OUT/trace5.log 2>&1
+python3 tools/kernel_stats.py $OUT/trace5 14 > $OUT/decode_kernel_stats.txt
+rm -rf $OUT/trace5
+python3 tools/ab_variants.py DEC_EDGE_VARIANT=1 DEC_EDGE_VARIANT=0 --rounds 2 --config cfg5 > $OUT/decode_ab.txt 2>/dev/null
+python3 tools/decode_precision_probe.py > $OUT/decode_precision.txt 2>/dev/null
+echo "decode done"
