@@ -159,3 +159,14 @@ def test_cli_recon_and_genzprot(tmp_path):
     assert "done: 16 structures on 1 GPU(s)" in gz.stdout
     xyz = np.load(os.path.join(tmp_path, "c", "logs", "generated_samples_0_best", "clitest_PED", "synthetic_L46_xyz_recon.npy"))
     assert np.isfinite(xyz).all() and not np.array_equal(xyz[0], xyz[1])          # members = different prior samples
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_runs_the_collectives_on_device_tensors():
+    """The `nccl` (RCCL) branch of codlad_amd.parallel on real device tensors, as far as one GPU allows: world size 1
+    (tests/nccl_single_rank_worker.py).  N > 1 over RCCL needs N GPUs and is the driver's to run."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_single_rank_worker.py"), str(_free_port())],
+                         env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "nccl single-rank collectives ok: backend nccl" in res.stdout
+    assert "ranks=1 backend=nccl" in res.stdout
