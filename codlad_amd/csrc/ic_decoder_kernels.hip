@@ -38,42 +38,87 @@ DEV kfloat_p as_uniform(const float *p) {
 
 DEV float swishf(float v) { return v * (1.0f / (1.0f + expf(-v))); }
 
-// One Linear layer for the 64 residues of a workgroup, its outputs dealt round-robin to the 4 waves:
-// emit(c, b[c] + sum_k W[c][k] * in[k]) for c = wave, wave + 4, ... < out_dim.  `in`: this lane's LDS column
-// (stride 64 floats), already activated if the layer's input is.  The caller separates layers with __syncthreads().
-template <int IN, typename Emit>
-DEV void wg_dense(const float *W, const float *b, int out_dim, const float *in, int wave, Emit emit) {
+// One Linear layer for the 64 residues of a workgroup, its outputs dealt round-robin to the 4 waves: output c = wave + 4 i
+// (i = 0, 1, ...) is emit(i, c, b[c] + sum_k W[c][k] * in[k]).  `in`: this lane's LDS column (stride 64 floats), already
+// activated if the layer's input is.
+//
+// Where the weights come from (round 3): the layer's [OUT][IN] matrix and bias are STAGED in LDS - fetched by the whole
+// workgroup as one coalesced read into registers while the previous layer computes (`fetch`), written to the staging
+// buffer between two barriers (`commit`), and read back as wave-uniform (broadcast) ds_read_b128.  Before, each output row
+// came through the scalar cache, one s_load + s_waitcnt per row with nothing to overlap it (scalar loads return out of
+// order, so a wave cannot keep a second row in flight): 10 exposed L2 round trips per layer per wave, 27 us for a kernel
+// with 3 us of arithmetic.  The arithmetic is unchanged: one fma chain over k in index order, then + bias.
+template <int IN> struct RowStride { static constexpr int v = (IN + 3) & ~3; };      // rows start 16-byte aligned
+template <int IN, int OUT> struct Staged {
+    static constexpr int STRIDE = RowStride<IN>::v, FLOATS = STRIDE * OUT + OUT, PER_THREAD = (FLOATS + 255) / 256;
+    float r[PER_THREAD];
+    DEV void fetch(const float *W, const float *b) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = (int)threadIdx.x + 256 * i, row = idx / STRIDE, k = idx - row * STRIDE;
+            float v = 0.f;
+            if (idx < STRIDE * OUT) { if (k < IN) v = W[row * IN + k]; }
+            else if (idx < FLOATS) v = b[idx - STRIDE * OUT];
+            r[i] = v;
+        }
+    }
+    // the caller puts a barrier before (nobody still reads the buffer) and after (everybody sees it)
+    DEV void commit(float *wbuf) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = (int)threadIdx.x + 256 * i;
+            if (idx < FLOATS) wbuf[idx] = r[i];
+        }
+    }
+};
+
+template <int IN, int OUT, typename Emit>
+DEV void wg_dense(const float *wbuf, const float *in, int wave, Emit emit) {
+    constexpr int STRIDE = RowStride<IN>::v;
     float x[IN];
 #pragma unroll
     for (int k = 0; k < IN; ++k) x[k] = in[k * 64];
-    kfloat_p Wk = as_uniform(W), bk = as_uniform(b);
-    for (int c = wave; c < out_dim; c += 4) {
-        kfloat_p wr = Wk + c * IN;
-        float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < IN; ++k) acc = fmaf(x[k], wr[k], acc);
-        emit(c, acc + bk[c]);
+    for (int i = 0; i < (OUT + 3) / 4; ++i) {
+        const int c = wave + 4 * i;
+        if (c < OUT) {
+            const float *wr = wbuf + c * STRIDE;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < IN; ++k) acc = fmaf(x[k], wr[k], acc);
+            emit(i, c, acc + wbuf[STRIDE * OUT + c]);
+        }
     }
 }
+#define STAGE_FLOATS(IN, OUT) (((IN + 3) & ~3) * (OUT) + (OUT))
 
 struct Scratch {
-    float *S, *V, *phi[2];
+    float *S, *V, *phi0;
+    size_t plane;
+    DEV float *phi(int which) const { return phi0 + (size_t)(which & 1) * plane; }   // (an array member indexed at run time lives in scratch memory)
 };
 DEV Scratch scratch_of(float *scr, int M) {
     Scratch s;
+    s.plane = (size_t)DF * M;
     s.S = scr;
-    s.V = scr + (size_t)DF * M;
-    s.phi[0] = scr + (size_t)2 * DF * M;
-    s.phi[1] = scr + (size_t)3 * DF * M;
+    s.V = scr + s.plane;
+    s.phi0 = scr + 2 * s.plane;
     return s;
 }
 
-// phi of a message block: inv_dense = Dense -> swish -> Dense on the raw state  (vae_model.py:360-363)
-DEV void write_phi(const codlad_decoder_weights &w, int blk, const float *s_col, float *t_col, float *phi, int n,
-                   bool active, int wave) {
-    wg_dense<DF>(w.inv0_w[blk], w.inv0_b[blk], DF, s_col, wave, [&](int c, float v) { t_col[c * 64] = swishf(v); });
+// phi of a message block: inv_dense = Dense -> swish -> Dense on the raw state  (vae_model.py:360-363).
+// `first` holds inv0's weights, fetched by the caller; the caller's last barrier is behind every reader of wbuf.
+DEV void write_phi(const codlad_decoder_weights &w, int blk, Staged<DF, DF> &first, float *wbuf, const float *s_col,
+                   float *t_col, float *phi, int n, bool active, int wave) {
+    first.commit(wbuf);
+    Staged<DF, DF> second;
+    second.fetch(w.inv1_w[blk], w.inv1_b[blk]);
     __syncthreads();
-    wg_dense<DF>(w.inv1_w[blk], w.inv1_b[blk], DF, t_col, wave, [&](int c, float v) {
+    wg_dense<DF, DF>(wbuf, s_col, wave, [&](int, int c, float v) { t_col[c * 64] = swishf(v); });
+    __syncthreads();
+    second.commit(wbuf);
+    __syncthreads();
+    wg_dense<DF, DF>(wbuf, t_col, wave, [&](int, int c, float v) {
         if (active) phi[(size_t)n * DF + c] = v;
     });
 }
@@ -82,25 +127,33 @@ DEV void write_phi(const codlad_decoder_weights &w, int blk, const float *s_col,
 __global__ __launch_bounds__(256) void dec_init_kernel(codlad_decoder_weights w, const float *z_q,
                                                       const int32_t *cg_z, int M, float *scr) {
     __shared__ float col[2 * DF][64];
+    __shared__ __attribute__((aligned(16))) float wbuf[STAGE_FLOATS(DF, DF)];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = blockIdx.x * 64 + lane;
     const bool active = n < M;
     const int nn = active ? n : M - 1;
     const Scratch sc = scratch_of(scr, M);
     float *s_col = &col[0][lane], *t_col = &col[DF][lane];
+    Staged<DF, DF> inv0;
+    inv0.fetch(w.inv0_w[0], w.inv0_b[0]);
     const int z = cg_z[nn];
     const bool mapped = w.map_out_w != nullptr;          // no map_out (the C2 model): z_q is the 36-wide latent itself
     const float q0 = mapped ? z_q[3 * nn] : 0.f, q1 = mapped ? z_q[3 * nn + 1] : 0.f, q2 = mapped ? z_q[3 * nn + 2] : 0.f;
-    kfloat_p mw = as_uniform(w.map_out_w), mb = as_uniform(w.map_out_b);
+    if (mapped) {
+        Staged<3, 36> mo;
+        mo.fetch(w.map_out_w, w.map_out_b);
+        mo.commit(wbuf);
+    }
+    __syncthreads();
     for (int c = wave; c < DF; c += 4) {
         float s;
-        if (c < 36) s = mapped ? fmaf(q2, mw[3 * c + 2], fmaf(q1, mw[3 * c + 1], q0 * mw[3 * c])) + mb[c]   // F.linear
+        if (c < 36) s = mapped ? fmaf(q2, wbuf[4 * c + 2], fmaf(q1, wbuf[4 * c + 1], q0 * wbuf[4 * c])) + wbuf[4 * 36 + c]   // F.linear
                                : z_q[(size_t)36 * nn + c];
         else s = w.res_embed[z * 4 + (c - 36)];
         s_col[c * 64] = s;
         if (active) sc.S[(size_t)c * M + n] = s;
     }
     __syncthreads();
-    write_phi(w, 0, s_col, t_col, sc.phi[0], n, active, wave);
+    write_phi(w, 0, inv0, wbuf, s_col, t_col, sc.phi(0), n, active, wave);
 }
 
 // a / d the way the compiler's IEEE expansion computes it (v_rcp, one refinement of the reciprocal, two of the
@@ -128,7 +181,7 @@ __global__ __launch_bounds__(64 * EDGE_WAVES) void dec_edge_exact_kernel(codlad_
     const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * EDGE_WAVES + wave);
     if (n >= M) return;                                // waves are independent: no workgroup barrier below
     const Scratch sc = scratch_of(scr, M);
-    const float *phi_in = sc.phi[blk & 1];
+    const float *phi_in = sc.phi(blk);
     float *my = filt[wave];
     const float xi = cg_xyz[3 * n], yi = cg_xyz[3 * n + 1], zi = cg_xyz[3 * n + 2];
     const int c = lane < DF ? lane : 0;
@@ -214,7 +267,7 @@ __global__ __launch_bounds__(64, 4) void dec_edge_kernel(codlad_decoder_weights 
     __shared__ int jsh[64];
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const Scratch sc = scratch_of(scr, M);
-    const float *phi_in = sc.phi[blk & 1];
+    const float *phi_in = sc.phi(blk);
     // B operand: lane (feature 32 b + c, k group h) holds W'[feature][8 h .. 8 h + 7], split; features >= 40 are zero
     f16x8 whi[2], wlo[2];
 #pragma unroll
@@ -337,11 +390,17 @@ __global__ __launch_bounds__(64, 4) void dec_edge_kernel(codlad_decoder_weights 
 // S += dense_blocks[blk](V)  (Sequential(swish, Linear, swish, Linear), vae_model.py:365-369, 489), phi for blk + 1
 __global__ __launch_bounds__(256) void dec_dense_kernel(codlad_decoder_weights w, int blk, int M, float *scr) {
     __shared__ float col[3 * DF][64];
+    __shared__ __attribute__((aligned(16))) float wbuf[STAGE_FLOATS(DF, DF)];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = blockIdx.x * 64 + lane;
     const bool active = n < M;
     const int nn = active ? n : M - 1;
     const Scratch sc = scratch_of(scr, M);
     float *a_col = &col[0][lane], *t_col = &col[DF][lane], *s_col = &col[2 * DF][lane];
+    Staged<DF, DF> st;
+    st.fetch(w.dense1_w[blk], w.dense1_b[blk]);
+    float s_old[DF / 4];                                  // this wave's rows of S, in flight under the two layers
+#pragma unroll
+    for (int i = 0; i < DF / 4; ++i) s_old[i] = sc.S[(size_t)(wave + 4 * i) * M + nn];
     {   // the workgroup's 64 x 40 sums are one contiguous block of V: coalesced dword reads, transposed into the columns
         const size_t first = (size_t)blockIdx.x * 64 * DF, total = (size_t)M * DF;
         for (int i = threadIdx.x; i < 64 * DF; i += 256) {
@@ -349,76 +408,109 @@ __global__ __launch_bounds__(256) void dec_dense_kernel(codlad_decoder_weights w
             col[i % DF][i / DF] = swishf(v);
         }
     }
+    st.commit(wbuf);
+    st.fetch(w.dense3_w[blk], w.dense3_b[blk]);
     __syncthreads();
-    wg_dense<DF>(w.dense1_w[blk], w.dense1_b[blk], DF, a_col, wave, [&](int c, float v) { t_col[c * 64] = swishf(v); });
+    wg_dense<DF, DF>(wbuf, a_col, wave, [&](int, int c, float v) { t_col[c * 64] = swishf(v); });
     __syncthreads();
-    wg_dense<DF>(w.dense3_w[blk], w.dense3_b[blk], DF, t_col, wave, [&](int c, float v) {
-        const float s = sc.S[(size_t)c * M + nn] + v;
+    st.commit(wbuf);
+    if (blk < 3) st.fetch(w.inv0_w[blk + 1], w.inv0_b[blk + 1]);
+    __syncthreads();
+    wg_dense<DF, DF>(wbuf, t_col, wave, [&](int i, int c, float v) {
+        const float s = s_old[i] + v;
         s_col[c * 64] = s;
         if (active) sc.S[(size_t)c * M + n] = s;
     });
     if (blk == 3) return;
     __syncthreads();
-    write_phi(w, blk + 1, s_col, a_col, sc.phi[(blk + 1) & 1], n, active, wave);
+    write_phi(w, blk + 1, st, wbuf, s_col, a_col, sc.phi(blk + 1), n, active, wave);
+}
+
+// One staged layer: barrier (the previous layer's columns are written, nobody reads the staging buffer any more), this
+// layer's weights into the buffer, the next layer's on their way into registers, barrier, compute.
+template <int IN, int OUT, typename Next, typename Emit>
+DEV void staged_layer(const Staged<IN, OUT> &cur, float *wbuf, const float *in, int wave, Next fetch_next, Emit emit) {
+    __syncthreads();
+    cur.commit(wbuf);
+    fetch_next();
+    __syncthreads();
+    wg_dense<IN, OUT>(wbuf, in, wave, emit);
 }
 
 // The output heads (vae_model.py:393-412 / 490-503): backbone angles and torsions, side-chain angles
 // (embedding or head), the four residual torsion blocks and the final torsion head; bond lengths from tables.
 // Every head is Sequential(swish, Linear, swish, Linear): `xs` holds swish of the running state, refreshed by the
-// wave that updates a row.
+// wave that updates a row; the running state itself (row c belongs to wave c mod 4 throughout) stays in that wave's
+// registers.
 template <bool ANGLE>
 __global__ __launch_bounds__(256) void dec_heads_kernel(codlad_decoder_weights w, const int32_t *cg_z, int M,
                                                        const float *S, float *ic) {
     constexpr int F = ANGLE ? DF + 10 : DF;
-    // rows: xs 0..55 | t 56..111 | u 112..167 | small 168..199
-    __shared__ float col[200][64];
+    // rows: xs 0..51 | u 52..103 | small 104..135
+    __shared__ float col[136][64];
+    __shared__ __attribute__((aligned(16))) float wbuf[STAGE_FLOATS(F, F)];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = blockIdx.x * 64 + lane;
     const bool active = n < M;
     const int nn = active ? n : M - 1;
-    float *xs = &col[0][lane], *t_col = &col[56][lane], *u_col = &col[112][lane], *sm = &col[168][lane];
+    float *xs = &col[0][lane], *u_col = &col[52][lane], *sm = &col[104][lane];
     float *bb_angle = sm + 3 * 64, *bb_tors = sm + 9 * 64, *sc_angle = sm + 12 * 64, *sc_tors = sm + 22 * 64;
+    Staged<DF, 3> a1;
+    a1.fetch(w.bb_ang1_w, w.bb_ang1_b);
     const int z = cg_z[nn];
-    for (int c = wave; c < DF; c += 4) {
-        const float s = S[(size_t)c * M + nn];
-        t_col[c * 64] = s;
-        xs[c * 64] = swishf(s);
+    float t[(F + 3) / 4];                                                           // rows wave, wave + 4, ... of the state
+#pragma unroll
+    for (int i = 0; i < DF / 4; ++i) {
+        const int c = wave + 4 * i;
+        t[i] = S[(size_t)c * M + nn];
+        xs[c * 64] = swishf(t[i]);
     }
-    __syncthreads();
-    wg_dense<DF>(w.bb_ang1_w, w.bb_ang1_b, 3, xs, wave, [&](int c, float v) { sm[c * 64] = swishf(v); });
-    __syncthreads();
-    wg_dense<3>(w.bb_ang3_w, w.bb_ang3_b, 3, sm, wave, [&](int c, float v) {
+    Staged<3, 3> a3;
+    staged_layer(a1, wbuf, xs, wave, [&] { a3.fetch(w.bb_ang3_w, w.bb_ang3_b); },
+                 [&](int, int c, float v) { sm[c * 64] = swishf(v); });
+    Staged<DF + 3, 3> t1;
+    staged_layer(a3, wbuf, sm, wave, [&] { t1.fetch(w.bb_tor1_w, w.bb_tor1_b); }, [&](int, int c, float v) {
         bb_angle[c * 64] = v;
         xs[(DF + c) * 64] = swishf(v);                                             // cat([S, bb_angle])
     });
-    __syncthreads();
-    wg_dense<DF + 3>(w.bb_tor1_w, w.bb_tor1_b, 3, xs, wave, [&](int c, float v) { sm[(6 + c) * 64] = swishf(v); });
-    __syncthreads();
-    wg_dense<3>(w.bb_tor3_w, w.bb_tor3_b, 3, sm + 6 * 64, wave, [&](int c, float v) { bb_tors[c * 64] = v; });
+    Staged<3, 3> t3;
+    staged_layer(t1, wbuf, xs, wave, [&] { t3.fetch(w.bb_tor3_w, w.bb_tor3_b); },
+                 [&](int, int c, float v) { sm[(6 + c) * 64] = swishf(v); });
+    Staged<F, F> r1;
+    Staged<DF, 10> s1;
+    staged_layer(t3, wbuf, sm + 6 * 64, wave, [&] {
+        if (ANGLE) s1.fetch(w.sc_ang1_w, w.sc_ang1_b);
+        else r1.fetch(w.tor1_w[0], w.tor1_b[0]);
+    }, [&](int, int c, float v) { bb_tors[c * 64] = v; });
     if (ANGLE) {
-        wg_dense<DF>(w.sc_ang1_w, w.sc_ang1_b, 10, xs, wave, [&](int c, float v) { u_col[c * 64] = swishf(v); });
-        __syncthreads();
-        wg_dense<10>(w.sc_ang3_w, w.sc_ang3_b, 10, u_col, wave, [&](int c, float v) {
+        Staged<10, 10> s3;
+        staged_layer(s1, wbuf, xs, wave, [&] { s3.fetch(w.sc_ang3_w, w.sc_ang3_b); },
+                     [&](int, int c, float v) { u_col[c * 64] = swishf(v); });
+        staged_layer(s3, wbuf, u_col, wave, [&] { r1.fetch(w.tor1_w[0], w.tor1_b[0]); }, [&](int i, int c, float v) {
             sc_angle[c * 64] = v;
-            t_col[(DF + c) * 64] = v;                                              // cat([S, sc_angle])
+            t[(F + 3) / 4 > DF / 4 ? DF / 4 + i : 0] = v;                           // cat([S, sc_angle]): row DF + c
             xs[(DF + c) * 64] = swishf(v);
         });
     } else {
         for (int k = wave; k < 10; k += 4) sc_angle[k * 64] = w.sc_angle_emb[z * 10 + k];
     }
-    __syncthreads();
+    Staged<F, 10> f1;
+#pragma unroll
     for (int b = 0; b < 4; ++b) {
-        wg_dense<F>(w.tor1_w[b], w.tor1_b[b], F, xs, wave, [&](int c, float v) { u_col[c * 64] = swishf(v); });
-        __syncthreads();
-        wg_dense<F>(w.tor3_w[b], w.tor3_b[b], F, u_col, wave, [&](int c, float v) {
-            const float t = t_col[c * 64] + v;
-            t_col[c * 64] = t;
-            xs[c * 64] = swishf(t);
+        Staged<F, F> r3;
+        staged_layer(r1, wbuf, xs, wave, [&] { r3.fetch(w.tor3_w[b], w.tor3_b[b]); },
+                     [&](int, int c, float v) { u_col[c * 64] = swishf(v); });
+        staged_layer(r3, wbuf, u_col, wave, [&] {
+            if (b < 3) r1.fetch(w.tor1_w[b + 1], w.tor1_b[b + 1]);
+            else f1.fetch(w.fin1_w, w.fin1_b);
+        }, [&](int i, int c, float v) {
+            t[i] += v;
+            xs[c * 64] = swishf(t[i]);
         });
-        __syncthreads();
     }
-    wg_dense<F>(w.fin1_w, w.fin1_b, 10, xs, wave, [&](int c, float v) { u_col[c * 64] = swishf(v); });
-    __syncthreads();
-    wg_dense<10>(w.fin3_w, w.fin3_b, 10, u_col, wave, [&](int c, float v) { sc_tors[c * 64] = v; });
+    Staged<10, 10> f3;
+    staged_layer(f1, wbuf, xs, wave, [&] { f3.fetch(w.fin3_w, w.fin3_b); },
+                 [&](int, int c, float v) { u_col[c * 64] = swishf(v); });
+    staged_layer(f3, wbuf, u_col, wave, [] {}, [&](int, int c, float v) { sc_tors[c * 64] = v; });
     __syncthreads();
     if (!active) return;
     float *o = ic + (size_t)n * 39;
