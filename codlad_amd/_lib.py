@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 9   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 10   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -114,6 +114,7 @@ _SIGS = {
     "codlad_cg_graph": (C.c_int, [P, P, C.c_int, C.c_float, P, P, P, P]),
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "codlad_ic_to_xyz_groups": (C.c_int, [P, C.c_int, C.c_int, P]),
+    "codlad_xyz_to_ic": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int, P, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, C.c_int, P]),
     "codlad_tp_conv": (C.c_int, [C.POINTER(TpConvArgs), P]),

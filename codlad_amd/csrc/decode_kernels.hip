@@ -227,3 +227,55 @@ extern "C" int codlad_ic_to_xyz_groups(const codlad_xyz_group *groups_dev, int n
                        groups_dev, n_groups, total_rows);
     return codlad_check_launch("codlad_ic_to_xyz_groups");
 }
+
+// ----------------------------------------------------------------------------------------------------------------------
+// The inverse direction, for building data sets from coordinates: the internal coordinates the reference
+// computes with mdtraj / numpy in build_ic_peptide_dataset (utils/protein_module.py:770-774 -> utils/utils_ic.py:141-196).
+// A "quad" names four atoms of a frame: ic = (|A1 - A2|, angle(A1 - A2, A3 - A2), dihedral(A1, A2, A3, A4)), angle and
+// dihedral reduced to [0, 2 pi) as protein_module.py:773 does; a quad with a negative index (a side-chain slot the
+// residue does not have) gives zeros.  The host tables say which atoms: backbone N = (N, CA, CA-, CA+), C = (C, CA, CA+, CA-),
+// O = (O, C, CA, N); side chain j = (core[j + 4], core[order[2]], core[order[1]], core[order[0]]).
+DEV float wrap_2pi(float a) {
+    const float two_pi = 6.283185307179586f;
+    float m = fmodf(a, two_pi);
+    if (m < 0.f) m += two_pi;
+    return m;
+}
+__global__ __launch_bounds__(256) void xyz_to_ic_kernel(const float *xyz, int n_frames, int n_atoms, const int32_t *quads,
+                                                       int n_quads, float *ic) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_frames * n_quads) return;
+    const int f = (int)(t / n_quads), q = (int)(t - (size_t)f * n_quads);
+    const int32_t *qa = quads + (size_t)q * 4;
+    float *o = ic + t * 3;
+    if (qa[0] < 0 || qa[1] < 0 || qa[2] < 0 || qa[3] < 0) { o[0] = o[1] = o[2] = 0.f; return; }
+    const float *fr = xyz + (size_t)f * n_atoms * 3;
+    auto at = [&](int i) { return v3(fr[3 * i], fr[3 * i + 1], fr[3 * i + 2]); };
+    const V3 p0 = at(qa[0]), p1 = at(qa[1]), p2 = at(qa[2]), p3 = at(qa[3]);
+    const V3 u = v3(p0.x - p1.x, p0.y - p1.y, p0.z - p1.z), w = v3(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z);
+    const float nu = sqrtf(dot3(u, u)), nw = sqrtf(dot3(w, w));
+    // angle_between (utils_ic.py:95-106) is arccos of the clipped dot product of the unit vectors; the same angle from
+    // atan2(|u x w|, u . w), which keeps fp32 accuracy where arccos loses it (angles near 0 and pi)
+    const V3 uxw = v3(u.y * w.z - u.z * w.y, u.z * w.x - u.x * w.z, u.x * w.y - u.y * w.x);
+    const float angle = atan2f(sqrtf(dot3(uxw, uxw)), dot3(u, w));
+    // dihedral (utils_ic.py:109-138): b1 normalised, rejections of b0 and b2 from it, atan2
+    const V3 b0 = u, b2 = v3(p3.x - p2.x, p3.y - p2.y, p3.z - p2.z);
+    const V3 b1 = v3(w.x / nw, w.y / nw, w.z / nw);
+    const float d0 = dot3(b0, b1), d2 = dot3(b2, b1);
+    const V3 v = v3(b0.x - b1.x * d0, b0.y - b1.y * d0, b0.z - b1.z * d0);
+    const V3 ww = v3(b2.x - b1.x * d2, b2.y - b1.y * d2, b2.z - b1.z * d2);
+    const V3 cr = v3(b1.y * v.z - b1.z * v.y, b1.z * v.x - b1.x * v.z, b1.x * v.y - b1.y * v.x);
+    o[0] = nu;
+    o[1] = angle;                                            // in [0, pi]: nothing to wrap
+    o[2] = wrap_2pi(atan2f(dot3(cr, ww), dot3(v, ww)));
+}
+
+extern "C" int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t *quads, int n_quads,
+                                float *ic_out, void *stream) {
+    CODLAD_REQUIRE(xyz && quads && ic_out, "null pointer");
+    CODLAD_REQUIRE(n_frames > 0 && n_atoms > 0 && n_quads > 0, "n_frames, n_atoms and n_quads must be positive");
+    const size_t total = (size_t)n_frames * n_quads;
+    hipLaunchKernelGGL(xyz_to_ic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       xyz, n_frames, n_atoms, quads, n_quads, ic_out);
+    return codlad_check_launch("codlad_xyz_to_ic");
+}

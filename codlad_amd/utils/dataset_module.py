@@ -1,6 +1,7 @@
 """Drop-in for the two pieces of the reference's utils/dataset_module.py the hot path touches:
 `get_norm_feature` (latent (de-)normalisation, dataset_module.py:230-256) and `CG_collate`'s batch
-schema (dataset_module.py:259-295).  The mdtraj-based loaders are out of scope."""
+schema (dataset_module.py:259-295), plus `load_dataset` (dataset_module.py:144-225) for multi-model PDB files, built on
+utils/dataset_builder.py instead of mdtraj (the .xtc branch, `single=False`, is not built: no reader for that format)."""
 import os
 
 import numpy as np
@@ -63,3 +64,31 @@ def CG_collate(dicts):
         else:
             batch[key] = torch.stack([d[key] for d in dicts], dim=0)
     return batch
+
+
+def load_dataset(data_path, params, single=True, device="cuda"):
+    """dataset_module.py:144-225 for `single=True`: `{data_path}.pdb` (a multi-model ensemble) -> (DataLoader of CG_collate
+    batches, info_dict, n_atoms, n_cgs, atomic_nums, topology of the interior residues).  `params`: the VAE's
+    modelparams (atom_cutoff, cg_cutoff, edgeorder).  The reference's file-specific trimming of thirteen PED entries
+    (dataset_module.py:167-179: their first and last residue dropped before anything else) is kept."""
+    from torch.utils.data import DataLoader
+
+    from . import dataset_builder as db
+    from .protein_module import info_from_residues
+    if not single:
+        raise NotImplementedError("load_dataset(single=False) reads .xtc trajectories; only multi-model PDB files are read here")
+    top, frames = db.read_pdb(f"{data_path}.pdb")
+    if os.path.basename(data_path) in _PED_TRIM_ENDS:
+        a, b = int(top.first_atom[1]), int(top.first_atom[top.n_residues - 1])
+        top, frames = top.subset_residues(1, top.n_residues - 1), frames[:, a:b]
+    info, n_cgs = info_from_residues(top.res_names, top.atom_names)
+    testset, _mapping = db.build_split_dataset(top, frames, params, prot_idx=0, device=device)
+    nfirst, nlast = len(top.atom_names[0]), len(top.atom_names[-1])
+    atomic_nums = top.atomic_nums()[nfirst:top.n_atoms - nlast]
+    loader = DataLoader(testset, batch_size=min(len(testset), 96), collate_fn=CG_collate, shuffle=False, drop_last=False)
+    return loader, {0: info}, top.n_atoms - nfirst - nlast, n_cgs, atomic_nums, top.subset_residues(1, top.n_residues - 1)
+
+
+_PED_TRIM_ENDS = ("PED00151e000", "PED00151e001", "PED00151e002", "PED00011e001", "PED00143e001", "PED00145e000",
+                  "PED00145e001", "PED00148e001", "PED00148e002", "PED00150e000", "PED00150e001", "PED00150e002",
+                  "PED00145e002")

@@ -6,11 +6,18 @@ residue names and, per residue, the atom names in file order - so the builder he
 (`info_from_residues`), and `read_pdb_topology` extracts them from a PDB file without mdtraj.  The reference writes
 generated trajectories through mdtraj as .xtc and .pdb (test.py:787-803); `write_pdb` writes the multi-model PDB
 directly (coordinates in Angstrom as they leave `ic_to_xyz`); the compressed .xtc format is not produced.
+
+The data-set builder of the same reference file (`build_ic_peptide_dataset`, `build_split_dataset`, `CGDataset`,
+`get_neighbor_list`, protein_module.py:567-951) lives in utils/dataset_builder.py and is re-exported here under the
+reference's names.
 """
 import numpy as np
 import torch
 
 from .ic_tables import atom_order_list, core_atoms
+from .dataset_builder import (CGDataset, RES2IDX, THREE_LETTER_TO_ONE, Topology, build_ic_peptide_dataset,  # noqa: F401
+                              build_split_dataset, read_pdb)
+from .dataset_builder import neighbor_list as get_neighbor_list  # noqa: F401
 
 
 def info_from_residues(res_names, atom_names):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 9
+#define CODLAD_ABI_VERSION 10
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -345,6 +345,13 @@ typedef struct {
     int32_t B, L, n_atoms, first_row;
 } codlad_xyz_group;
 int codlad_ic_to_xyz_groups(const codlad_xyz_group *groups, int n_groups, int total_rows, void *stream);
+
+/* The inverse, for building data sets from coordinates (utils/protein_module.py:770-774: get_backbone_ic / get_sidechain_ic
+ * of utils/utils_ic.py:141-196, there on mdtraj / numpy).  xyz [n_frames][n_atoms][3]; quads int32 [n_quads][4] = atoms
+ * (A1, A2, A3, A4) of each internal coordinate, any index < 0 = the slot does not exist (zeros); ic_out
+ * [n_frames][n_quads][3] = (|A1 - A2|, angle(A1 - A2, A3 - A2), dihedral(A1, A2, A3, A4)), angle and dihedral in [0, 2 pi). */
+int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t *quads, int n_quads, float *ic_out,
+                     void *stream);
 
 /* Tuning switches (speed only: every setting computes the same values).  Defaults suit MI355X; the environment
  * variable of the same name (CODLAD_ prefix, upper case) sets the initial value.

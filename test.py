@@ -8,10 +8,10 @@ directories of utils/model_module.py), the call sequence build_model -> create_d
 p_sample_loop -> get_norm_feature -> latent_decode -> ic_to_xyz, and the output directory.
 Different by design: all ensemble members of a batch of frames are sampled in ONE launch set (the
 reference loops over them); the C2 prior call that only supplies `mask` (test.py:495) is replaced by
-the length mask; metrics and mdtraj I/O (out of scope) are replaced by saving coordinates as .npy.
-Data: `--data_process --data_files f.pkl ...` (pickled per-frame dicts, as the reference's
---data_process branch reads them) or `--synthetic`
-(no PED/PDB/Atlas files ship with the reference).
+the length mask; mdtraj I/O is replaced by saving coordinates as .npy (and multi-model PDB, --save_pdb).
+Data: `--pdb_files ens.pdb ...` (multi-model PDB ensembles -> the reference's load_dataset without mdtraj),
+`--data_process --data_files f.pkl ...` (pickled per-frame dicts, as the reference's --data_process branch reads
+them) or `--synthetic` (no PED/PDB/Atlas files ship with the reference).
 """
 import argparse
 import os
@@ -124,8 +124,23 @@ def iter_batches(args):
                     batch.update(synth.make_atoms(prot, range(a, b), seed=1000 + i))
                 yield out, batch, prot["info"]
         return
+    if getattr(args, "pdb_files", None):
+        # reference test.py:424-436 -> load_dataset(f"{dir}/{name}", params): a multi-model PDB ensemble, here without
+        # mdtraj (utils/dataset_builder.py; internal coordinates by codlad_xyz_to_ic).  Cut-offs: the VAE's modelparams
+        # (the shipped ones: atom 9.0, CG 21.0, bond order 2), overridable on the command line.
+        from codlad_amd.utils.dataset_module import load_dataset
+        params = {"atom_cutoff": args.atom_cutoff, "cg_cutoff": args.cg_cutoff, "edgeorder": args.edgeorder}
+        for path in args.pdb_files:
+            stem = path[:-4] if path.endswith(".pdb") else path
+            loader, info_dict, _n_atoms, _n_cgs, _z, top = load_dataset(stem, params, device="cuda")
+            n_batches = len(loader)
+            for c, batch in enumerate(loader):
+                out = output_name(os.path.basename(stem), c, n_batches)
+                _TOPOLOGY[out] = (["GLY"] + top.res_names + ["GLY"], [["CA"]] + top.atom_names + [["CA"]])
+                yield out, batch, info_dict[0]
+        return
     if not args.data_process:
-        raise SystemExit("pdb/xtc loading needs mdtraj (out of scope): use --data_process --data_files ... or --synthetic")
+        raise SystemExit("xtc loading is not built: use --pdb_files (multi-model PDB), --data_process --data_files ... or --synthetic")
     for path in args.data_files:
         with open(path, "rb") as f:
             testset, info = pickle.load(f)
@@ -361,4 +376,9 @@ if __name__ == "__main__":
     p.add_argument("--synthetic_frames", type=int, default=10)
     p.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (no checkpoints ship)")
     p.add_argument("--save_pdb", action="store_true", help="also write the generated ensemble as a multi-model PDB")
+    p.add_argument("--pdb_files", nargs="*", default=None,
+                   help="multi-model PDB ensembles to build the test set from (the reference's load_dataset, without mdtraj)")
+    p.add_argument("--atom_cutoff", type=float, default=9.0)
+    p.add_argument("--cg_cutoff", type=float, default=21.0)
+    p.add_argument("--edgeorder", type=int, default=2)
     main(p.parse_args())
