@@ -11,12 +11,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
 SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_tile_kernels.hip",
            "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
-           "ic_decoder_kernels.hip", "encoder_kernels.hip", "metrics_kernels.hip"]
+           "ic_decoder_kernels.hip", "encoder_kernels.hip", "encoder_mfma_kernel.hip", "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
 # and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
 EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip": ["-ffp-contract=off"], "decode_kernels.hip": ["-ffp-contract=off"],
                "ic_decoder_kernels.hip": ["-ffp-contract=off"],
                "metrics_kernels.hip": ["-ffp-contract=off"], "encoder_kernels.hip": ["-ffp-contract=off"],
+               "encoder_mfma_kernel.hip": ["-ffp-contract=off"],
                # SLP packing of the shuffle-reduction adds blocks their fusion into v_add_f32_dpp;
                # the packed math that pays (GELU) is written out explicitly in common.h
                # -fno-honor-nans: min/max on MFMA results otherwise get a canonicalising v_max x,x
@@ -26,7 +27,7 @@ EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip":
                "edge_msg_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_upd_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "node_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_args.h"), os.path.join(CSRC, "node_args.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "encoder_common.h"), os.path.join(CSRC, "edge_args.h"), os.path.join(CSRC, "node_args.h"),
            os.path.join(HERE, "..", "include", "codlad_hip.h")]
 
 

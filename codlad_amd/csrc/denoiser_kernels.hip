@@ -600,6 +600,7 @@ extern "C" int codlad_set_option(int option, int value) {
 static int edge_tile_max_nodes() { return option_or(CODLAD_OPT_EDGE_TILE_MAX_NODES, "CODLAD_EDGE_TILE_MAX_NODES", 1 << 30); }
 static int nodeq_max_tiles() { return option_or(CODLAD_OPT_NODEQ_MAX_TILES, "CODLAD_NODEQ_MAX_TILES", 256); }
 int dec_edge_variant() { return option_or(CODLAD_OPT_DEC_EDGE_VARIANT, "CODLAD_DEC_EDGE_VARIANT", 0); }
+int tp_conv_variant() { return option_or(CODLAD_OPT_TP_CONV_VARIANT, "CODLAD_TP_CONV_VARIANT", 0); }
 
 // node_wide_kernels.hip
 void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st);

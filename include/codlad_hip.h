@@ -297,7 +297,8 @@ int codlad_cg_graph(const float *cg_xyz, const int32_t *sample_range, int M, flo
  *   attr_recv_first: 1 = fc sees [e | h_recv[:12] | h_snd[:12]] (intra graphs, bead -> atom), 0 = [e | h_snd | h_recv]
  *     (atom -> bead: reference vae_model.py:140-142 passes the same concatenation to both cross directions);
  *   out [n_recv][12 (depth + 2)]: accumulate 0: out = pad(h_recv) + mean, 1: out += mean (the layer's second update);
- *   group: lanes per receiving node (64, 16 or 1: pick >= the typical degree; any degree is correct with any group). */
+ *   group: lanes per receiving node (64, 16 or 1: pick >= the typical degree; any degree is correct with any group);
+ *     64 selects the matrix-pipe kernel (CODLAD_OPT_TP_CONV_VARIANT). */
 typedef struct {
     const int32_t *ptr, *snd;
     int32_t n_recv;
@@ -362,10 +363,14 @@ int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t 
  *   (slot 2 is unused: the round-2 header reserved it for a captured / persistent step loop that was never built)
  *   CODLAD_OPT_DEC_EDGE_VARIANT  IC decoder messages: 0 = one sine / cosine + recurrence, 15 -> 40 filter on the f16 matrix
  *                                pipe (split fp16, fp32-equivalent); 1 = 15 library sines and fp32 FMAs (round-2 kernel).
- *                                NOT bit-identical to each other (both within the decoder's parity tolerance) */
+ *                                NOT bit-identical to each other (both within the decoder's parity tolerance)
+ *   CODLAD_OPT_TP_CONV_VARIANT   codlad_tp_conv with group = 64: 0 = fc.0 / fc.3 on the f16 matrix pipe (split fp16,
+ *                                fp32-equivalent; a wave per receiving node, 32 edges per step); 1 = the scalar-operand
+ *                                kernel that also serves groups 1 and 16.  Not bit-identical to each other either */
 #define CODLAD_OPT_NODEQ_MAX_TILES 0
 #define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
 #define CODLAD_OPT_DEC_EDGE_VARIANT 3
+#define CODLAD_OPT_TP_CONV_VARIANT 4
 #define CODLAD_N_OPTIONS 8
 int codlad_set_option(int option, int value);
 

@@ -225,6 +225,35 @@ def test_hip_encoder_matches_oracle(L, frames):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("scale", [1.0, 30.0, 1.0 / 30.0])
+def test_tp_conv_variants_and_weight_magnitudes(variant, scale):
+    """codlad_tp_conv's kernels (CODLAD_OPT_TP_CONV_VARIANT: 0 = all graphs on the matrix-pipe kernel, 1 = all on the
+    scalar-operand kernel, 2 = matrix pipe for the intra-level graphs only) against the oracle, also with fc weights thirty
+    times larger / smaller than the initialisation's (the matrix-pipe kernel splits weights and activations into fp16
+    halves behind fixed power-of-two scales: hidden activations and per-edge weights then span 2^-10 .. 2^10)."""
+    from codlad_amd import _lib
+    from codlad_amd.encoder import Encoder, Prior
+    sd = {k: (v * scale if ".fc." in k and k.endswith("weight") else v) for k, v in synth.encoder_state_dict(33).items()}
+    psd = {k: (v * scale if ".fc." in k and k.endswith("weight") else v) for k, v in synth.prior_state_dict(34).items()}
+    prot = synth.make_protein(46, 71, n_frames=2)
+    batch = synth.make_batch(prot)
+    atoms = synth.make_atoms(prot, seed=9)
+    args = (atoms["nxyz"][:, 0], atoms["nxyz"][:, 1:], batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:],
+            atoms["CG_mapping"], atoms["nbr_list"], batch["CG_nbr_list"])
+    ref = e3.encoder_forward(sd, *args)
+    mu_ref, sg_ref = e3.prior_forward(psd, args[2], args[3], args[6])
+    _lib.set_option(_lib.OPT_TP_CONV_VARIANT, variant)
+    try:
+        got = Encoder(sd, DEV).forward(*args)
+        mu, sg = Prior(psd, DEV).forward(args[2], args[3], args[6])
+    finally:
+        _lib.set_option(_lib.OPT_TP_CONV_VARIANT, 0)
+    assert rel_err(got, ref) < 1e-5, rel_err(got, ref)
+    assert rel_err(mu, mu_ref) < 1e-5 and rel_err(sg, sg_ref) < 1e-5
+
+
+@pytest.mark.gpu
 def test_genzprot_and_recon_models_run_end_to_end():
     """The module mirrors on the device: C2 (`get_latent_cg` -> `latent_decode` on the 36-wide latent, with the shipped
     prior's trained weights) and an N6 VQ-VAE with its encoder (`get_latent_wovq` -> `latent_decode`) against the oracle."""
