@@ -147,7 +147,10 @@ class Workload:
         """CA traces + noise (HBM) -> all-atom coordinates (HBM) for this rank's structures."""
         self.prepass()
         x0 = self.latent if self.decode_only else self.den.sample(self.job, self.x_T, self.noise, self.tables)
-        idx, zq, _lat = self.dec.vq(x0)
+        return self.decode(x0)
+
+    def decode(self, x0, normalised=True):
+        idx, zq, _lat = self.dec.vq(x0, normalised=normalised)
         ic = self.dec.ic_decode(zq, self.cg_z, self.cg_xyz, csr=self.csr)
         groups = []
         for start, count, prot, ca in self.groups:
@@ -192,6 +195,43 @@ class Workload:
                 launch(which)
             res[name] = self.timed(lambda: launch(which), n_launch)
         return res
+
+
+def recon_from_atoms(wl):
+    """cfg 5 the way `test.py --experiment recon` runs it (reference test.py:501): the VQ-VAE's e3nn encoder on every
+    frame's atoms, map_in, and the frame's latent decoded once per ensemble member.  Synthetic atoms
+    (codlad_amd.synth.make_atoms) and encoder weights; -> seconds per pass over the job's structures."""
+    from codlad_amd import synth
+    from codlad_amd.utils.model_module import build_vae, load_decoder_state
+    cfg = wl.cfg
+    vae = build_vae(cfg["vae_type"], with_encoder=True)
+    sd = synth.vqvae_state_dict(cfg["vae_type"], cfg["dataname"], VAE_SEED)
+    sd.update({"encoder." + k: v for k, v in synth.encoder_state_dict(778).items()})
+    sd.update({k: v for k, v in vae.state_dict().items() if k.endswith(".offset")})
+    load_decoder_state(vae, sd)
+    vae = vae.to(wl.device).eval()
+    batches, first_row, row = [], {}, 0
+    for p, prot in enumerate(wl.proteins):
+        b = synth.make_batch(prot)
+        b.update(synth.make_atoms(prot, seed=p))
+        batches.append({k: (v.to(wl.device) if torch.is_tensor(v) else v) for k, v in b.items()})
+        for f in range(cfg["n_frames"]):
+            first_row[(p, f)] = row
+            row += prot["n_cg"]
+    src = torch.cat([first_row[(p, f)] + torch.arange(wl.proteins[p]["n_cg"]) for p, f, _m in wl.units]).to(wl.device)
+    n_atoms = sum(int(b["nxyz"].shape[0]) for b in batches)
+
+    def run():
+        wl.prepass()
+        lat = torch.cat([vae.get_latent_wovq(b)[0].reshape(-1, 3) for b in batches], 0)   # [frames x L, 3], one per frame
+        return wl.decode(lat[src], normalised=False)
+
+    def encode():
+        return [vae.get_latent_wovq(b)[0] for b in batches]
+
+    run()
+    return {"seconds": wl.timed(run, 5), "encoder_seconds": wl.timed(encode, 5), "frames": row and len(first_row),
+            "atoms": n_atoms, "directed_atom_edges": sum(2 * int(b["nbr_list"].shape[0]) for b in batches)}
 
 
 PROBE_KINDS = ((0, "message"), (1, "edge_update"), (2, "message_hoisted"), (3, "edge_update_hoisted"))
@@ -385,6 +425,15 @@ def main():
     extra = {}
     if rank == 0 and world == 1:
         extra["prepass_ms"] = wl.timed(wl.prepass, 3) * 1e3     # share of ms_per_step spent before the first DDPM step
+        if wl.decode_only:
+            r = recon_from_atoms(wl)
+            extra["recon_from_atoms"] = {
+                "value": wl.n_structures / r["seconds"], "unit": "structures/s", "ms_per_step": r["seconds"] * 1e3,
+                "encoder_ms": r["encoder_seconds"] * 1e3, "frames": r["frames"], "atoms": r["atoms"],
+                "directed_atom_edges": r["directed_atom_edges"],
+                "note": "the same structures as test.py --experiment recon produces them: e3nn encoder on every frame's "
+                        "(synthetic) atoms + map_in, the frame's latent decoded once per ensemble member; `value` above "
+                        "is the decoder tail alone (BASELINE configuration 5 isolates the decoder / codebook kernels)"}
     if not wl.decode_only:
         kern = wl.time_dominant_kernel()          # back to back, alone on the chip
         insitu = probe_edge_kernels(wl)           # inside the job

@@ -115,6 +115,7 @@ _SIGS = {
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "codlad_ic_to_xyz_groups": (C.c_int, [P, C.c_int, C.c_int, P]),
     "codlad_xyz_to_ic": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int, P, P]),
+    "codlad_receiver_csr": (C.c_int, [P, C.c_int, C.c_int, C.c_int, P, P, P, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, C.c_int, P]),
     "codlad_tp_conv": (C.c_int, [C.POINTER(TpConvArgs), P]),

@@ -269,46 +269,41 @@ __global__ __launch_bounds__(64) void tp_conv_kernel(codlad_tp_conv_args a) {
     (void)D_IN;
 }
 
-// y = W2 act(W1 x + b1) + b2 per row, one thread per row (x gathered through `index` if given); weights through the
-// scalar cache.  act: 0 tanh, 1 relu.  Used for the encoder's dense head, map_in and the prior's mu / sigma heads.
+// y = W2 act(W1 x + b1) + b2 per row: 64 rows per workgroup (lane = row), the outputs of a layer dealt round-robin to its
+// 4 waves (a single wave walking all 72 output rows one scalar-cache round trip after the other took 70-100 us for a few
+// hundred rows); weights through the scalar cache, the hidden vector through LDS columns.  act: 0 tanh, 1 relu.  Used for
+// the encoder's dense head, map_in and the prior's mu / sigma heads.
 template <int IN>
-__global__ __launch_bounds__(64) void mlp_rows_kernel(const float *x, int n, const float *w1, const float *b1, int hidden,
-                                                     const float *w2, const float *b2, int out_dim, int act, int mode,
-                                                     float *y) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void mlp_rows_kernel(const float *x, int n, const float *w1, const float *b1, int hidden,
+                                                      const float *w2, const float *b2, int out_dim, int act, int mode,
+                                                      float *y) {
+    __shared__ float hcol[36][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * 64 + lane;
     const int ii = i < n ? i : n - 1;
     float in[IN];
 #pragma unroll
     for (int k = 0; k < IN; ++k) in[k] = x[(size_t)ii * IN + k];
     kfloat_p W1 = uni(w1), B1 = uni(b1), W2 = uni(w2), B2 = uni(b2);
-    float h[36];
     if (hidden > 0) {
-#pragma unroll 1
-        for (int o = 0; o < 36; ++o) {
-            float acc = 0.f;
-            if (o < hidden) {
-                acc = B1[o];
+        for (int o = wave; o < hidden; o += 4) {
+            float acc = B1[o];
 #pragma unroll
-                for (int k = 0; k < IN; ++k) acc = fmaf(in[k], W1[o * IN + k], acc);
-                acc = act == 0 ? tanhf(acc) : fmaxf(acc, 0.f);
-            }
-            // dynamic index into a register array would go to scratch: select instead
-#pragma unroll
-            for (int q = 0; q < 36; ++q) h[q] = q == o ? acc : h[q];
+            for (int k = 0; k < IN; ++k) acc = fmaf(in[k], W1[o * IN + k], acc);
+            hcol[o][lane] = act == 0 ? tanhf(acc) : fmaxf(acc, 0.f);
         }
+        __syncthreads();
     }
-    if (i >= n) return;
-    for (int o = 0; o < out_dim; ++o) {
+    for (int o = wave; o < out_dim; o += 4) {
         float acc = B2[o];
         if (hidden > 0) {
-#pragma unroll
-            for (int k = 0; k < 36; ++k) acc = k < hidden ? fmaf(h[k], W2[o * hidden + k], acc) : acc;
+            for (int k = 0; k < hidden; ++k) acc = fmaf(hcol[k][lane], W2[o * hidden + k], acc);
         } else {
 #pragma unroll
             for (int k = 0; k < IN; ++k) acc = fmaf(in[k], W2[o * IN + k], acc);
         }
         if (mode == 1) acc = 1e-9f + expf(acc / 2.0f);             // prior: H_sigma = 1e-9 + exp(logvar / 2)
-        y[(size_t)i * out_dim + o] = acc;
+        if (i < n) y[(size_t)i * out_dim + o] = acc;
     }
 }
 
@@ -334,6 +329,73 @@ __global__ void embed_rows_kernel(const float *table, const int *idx, int n, int
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * width) return;
     out[i] = table[(size_t)idx[i / width] * width + i % width];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Receivers' CSR of a pair list (the reference's make_directed + the grouping its scatter does, models/gcn_nn.py:54-64):
+// histogram -> scan -> fill -> per-receiver sort by sender, so that the edge order inside a receiver (and with it the
+// rounding of its mean) is a function of the graph alone, not of the atomics' arrival order.
+//   work: degA [n] | degB [n] | flags [2] | tmp [2 E]
+__global__ void csr_hist_kernel(const int64_t *pairs, int E, int n, int *work) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int a = (int)pairs[2 * (size_t)e], b = (int)pairs[2 * (size_t)e + 1];
+    atomicAdd(work + a, 1);
+    atomicAdd(work + n + b, 1);
+    if (a > b) work[2 * n] = 1;            // benign race: every writer stores 1
+    if (b > a) work[2 * n + 1] = 1;
+}
+
+// one workgroup: ptr = exclusive scan of degA (+ degB when the list holds one direction only); degA becomes the fill cursor
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int n, int mode, int *work, int *ptr) {
+    __shared__ int part[1024];
+    const int both = mode == 0 && !(work[2 * n] && work[2 * n + 1]);
+    const int per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += work[i] + (both ? work[n + i] : 0);
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        const int d = work[i] + (both ? work[n + i] : 0);
+        ptr[i] = run;
+        work[i] = run;
+        run += d;
+    }
+    if (threadIdx.x == 1023) ptr[n] = part[1023];
+    if (threadIdx.x == 0) work[2 * n] = both;                   // the fill reads the decision from here
+}
+
+__global__ void csr_fill_kernel(const int64_t *pairs, int E, int n, int *work) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int a = (int)pairs[2 * (size_t)e], b = (int)pairs[2 * (size_t)e + 1];
+    int *tmp = work + 2 * n + 2;
+    tmp[atomicAdd(work + a, 1)] = b;
+    if (work[2 * n]) tmp[atomicAdd(work + b, 1)] = a;
+}
+
+// one wave per receiver: senders ascending (rank sort; equal senders keep their slots' order)
+__global__ __launch_bounds__(256) void csr_sort_kernel(int n, const int *ptr, const int *work, int *snd) {
+    const int node = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (node >= n) return;
+    const int *tmp = work + 2 * n + 2;
+    const int e0 = ptr[node], deg = ptr[node + 1] - e0;
+    for (int i = lane; i < deg; i += 64) {
+        const int key = tmp[e0 + i];
+        int rank = 0;
+        for (int j = 0; j < deg; ++j) {
+            const int k = tmp[e0 + j];
+            rank += (k < key) || (k == key && j < i);
+        }
+        snd[e0 + rank] = key;
+    }
 }
 
 template <int DEPTH>
@@ -366,13 +428,28 @@ extern "C" int codlad_tp_conv(const codlad_tp_conv_args *a, void *stream) {
 
 extern "C" int codlad_tp_conv_args_size(void) { return (int)sizeof(codlad_tp_conv_args); }
 
+extern "C" int codlad_receiver_csr(const int64_t *pairs, int n_pairs, int n_nodes, int mode, int32_t *ptr, int32_t *snd,
+                                   int32_t *work, void *stream) {
+    CODLAD_REQUIRE(pairs && ptr && snd && work, "null pointer");
+    CODLAD_REQUIRE(n_pairs > 0 && n_nodes > 0 && (mode == 0 || mode == 1), "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t e = hipMemsetAsync(work, 0, sizeof(int32_t) * (2 * (size_t)n_nodes + 2), st);
+    if (e != hipSuccess) { codlad_set_error("codlad_receiver_csr: %s", hipGetErrorString(e)); return (int)e; }
+    const dim3 per_pair((n_pairs + 255) / 256), block(256);
+    hipLaunchKernelGGL(csr_hist_kernel, per_pair, block, 0, st, pairs, n_pairs, n_nodes, work);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, n_nodes, mode, work, ptr);
+    hipLaunchKernelGGL(csr_fill_kernel, per_pair, block, 0, st, pairs, n_pairs, n_nodes, work);
+    hipLaunchKernelGGL(csr_sort_kernel, dim3((n_nodes + 3) / 4), block, 0, st, n_nodes, ptr, work, snd);
+    return codlad_check_launch("codlad_receiver_csr");
+}
+
 extern "C" int codlad_mlp_rows(const float *x, int n, int in_dim, const float *w1, const float *b1, int hidden,
                                const float *w2, const float *b2, int out_dim, int act, int mode, float *y, void *stream) {
     CODLAD_REQUIRE(x && w2 && b2 && y && n > 0, "bad arguments");
     CODLAD_REQUIRE(hidden == 0 || (w1 && b1 && hidden <= 36), "hidden layer of at most 36 units");
     CODLAD_REQUIRE(out_dim > 0 && out_dim <= 36 && (act == 0 || act == 1) && (mode == 0 || mode == 1), "bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((n + 63) / 64), block(64);
+    const dim3 grid((n + 63) / 64), block(256);
     if (in_dim == 84) hipLaunchKernelGGL(mlp_rows_kernel<84>, grid, block, 0, st, x, n, w1, b1, hidden, w2, b2, out_dim, act, mode, y);
     else if (in_dim == 48) hipLaunchKernelGGL(mlp_rows_kernel<48>, grid, block, 0, st, x, n, w1, b1, hidden, w2, b2, out_dim, act, mode, y);
     else if (in_dim == 36) hipLaunchKernelGGL(mlp_rows_kernel<36>, grid, block, 0, st, x, n, w1, b1, hidden, w2, b2, out_dim, act, mode, y);

@@ -22,8 +22,11 @@
 // The packed weights (13 blocks x 3 k-steps x (hi, lo) x 1 KB + fc.0's 12 KB = 90 KB for depth 2) live in LDS for the
 // workgroup's lifetime; workgroups are persistent (one per CU, 8 waves).
 //
-// Powers of two keep the fp16 halves in range: operands are scaled by S_IN = 8 (activations) and S_W = 64 (weights) before
-// the split (their `lo` halves would otherwise be fp16 subnormals) and the products descaled exactly.
+// Powers of two keep the fp16 halves in range whatever the magnitudes are: every operand is scaled before the split so
+// that its largest element lands in a fixed binade - the two weight matrices once per workgroup (largest |w| -> [256, 512)),
+// an edge's 37 fc inputs and its 36 hidden activations per edge (largest -> [8, 16); a column of the B operand is one
+// edge, so the scale is a per-lane number) - and the products are descaled exactly; the descale of fc.3 rides on the
+// factor that zeroes the inputs of a lane without an edge, so it costs nothing.
 #include "encoder_common.h"
 
 int num_cu();                                       // denoiser_kernels.hip
@@ -31,8 +34,13 @@ void set_max_lds(const void *fn, size_t bytes);     // denoiser_kernels.hip
 
 namespace {
 
-constexpr float S_IN = 8.0f, S_W = 64.0f;
 constexpr int MF_WAVES = 8;
+
+// 2^(target - floor(log2 m)): the power of two that moves m (> 0) into [2^target, 2^(target + 1))
+DEV float pow2_scale(float m, int target) {
+    const int e = (int)((__float_as_uint(fmaxf(m, 1e-30f)) >> 23) & 0xff) - 127;
+    return __uint_as_float((unsigned)(127 + target - e) << 23);
+}
 
 struct RowSpec {
     int idx;          // row of fc.3 (weight index of the tensor product), -1: a zero row
@@ -78,7 +86,7 @@ DEV RowSpec row_spec(int depth, int tile, int half, int i) {
 }
 
 // Hidden unit behind k-slot q (0..23) of lane half hb of fc.3's contraction: the half's own rows of fc.0's result, in
-// the order they sit in its registers.  -1: zero column, -2: the bias column (the lane supplies S_IN there).
+// the order they sit in its registers.  -1: zero column, -2: the bias column (the lane supplies its scale there).
 DEV int hidden_of_slot(int hb, int q) {
     if (q < 16) return 8 * (q >> 2) + (q & 3) + 4 * hb;      // block 0 of fc.0: rows (r & 3) + 8 (r >> 2) + 4 h
     if (hb == 0) return q < 20 ? 32 + (q - 16) : -1;          // block 1, rows 0-3: units 32-35
@@ -143,6 +151,30 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
 
+    // ---- the weight matrices' scales (largest |w| or |b| of fc.3 over the rows this depth uses, of fc.0), once per workgroup
+    float *scales = out_sh + MF_WAVES * 48;                    // [0] fc.3, [1] fc.0, then the waves' partial maxima
+    {
+        constexpr int N3 = DEPTH == 0 ? 192 : (DEPTH == 1 ? 288 : 384);
+        float m3 = 0.f, m0 = 0.f;
+        for (int i = threadIdx.x; i < N3 * 36; i += 64 * MF_WAVES) m3 = fmaxf(m3, fabsf(a.fc3_w[i]));
+        for (int i = threadIdx.x; i < N3; i += 64 * MF_WAVES) m3 = fmaxf(m3, fabsf(a.fc3_b[i]));
+        for (int i = threadIdx.x; i < 36 * 36; i += 64 * MF_WAVES) m0 = fmaxf(m0, fabsf(a.fc0_w[i]));
+        for (int i = threadIdx.x; i < 36; i += 64 * MF_WAVES) m0 = fmaxf(m0, fabsf(a.fc0_b[i]));
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            m3 = fmaxf(m3, __shfl_xor(m3, m, 64));
+            m0 = fmaxf(m0, __shfl_xor(m0, m, 64));
+        }
+        if (lane == 0) { scales[2 + 2 * wave] = m3; scales[3 + 2 * wave] = m0; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 0; w < MF_WAVES; ++w) { m3 = fmaxf(m3, scales[2 + 2 * w]); m0 = fmaxf(m0, scales[3 + 2 * w]); }
+            scales[0] = pow2_scale(m3, 8);
+            scales[1] = pow2_scale(m0, 8);
+        }
+        __syncthreads();
+    }
+    const float S_W3 = scales[0], S_W0 = scales[1];
     // ---- pack the weights, once per workgroup: fragment (block, k-step) of lane l = row (l & 31), k-slots 8 (l >> 5) + 0..7
     for (int f = threadIdx.x; f < (NT + 2) * 3 * 64; f += 64 * MF_WAVES) {
         const int l = f & 63, blk = (f >> 6) / 3, ks = (f >> 6) % 3;
@@ -155,7 +187,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                 const int m = hidden_of_slot(hb, 8 * ks + j);
                 float w = 0.f;
                 if (rs.idx >= 0 && m != -1) w = m >= 0 ? a.fc3_w[rs.idx * 36 + m] : a.fc3_b[rs.idx];
-                v[j] = (S_W * rs.factor) * w;
+                v[j] = (S_W3 * rs.factor) * w;
             }
             store_frag(A3 + (blk * 3 + ks) * 128 + l, v);
         } else {                                                    // fc.0: rows = hidden units, k-slot = input index, 36 = bias
@@ -165,7 +197,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                 const int k = 16 * ks + 8 * hb + j;
                 float w = 0.f;
                 if (m < 36 && k <= 36) w = k < 36 ? a.fc0_w[m * 36 + k] : a.fc0_b[m];
-                v[j] = S_W * w;
+                v[j] = S_W0 * w;
             }
             store_frag(A0 + ((blk - NT) * 3 + ks) * 128 + l, v);
         }
@@ -175,12 +207,11 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
     kfloat_p emb0_w = uni(a.emb0_w), emb0_b = uni(a.emb0_b), emb3_w = uni(a.emb3_w), emb3_b = uni(a.emb3_b);
     const float step = a.smear_stop / 7.0f, coeff = -0.5f / (step * step);
     float *my_out = out_sh + wave * 48;
-    // path coefficients sqrt((2 l_out + 1) / sum of mul_in1 over the paths into the same output block), descaled
-    constexpr float DESCALE = 1.0f / (S_IN * S_W);
-    constexpr float C0E = (DEPTH == 0 ? 0.28867513459481287f : 0.25f) * DESCALE;
-    constexpr float C1O = (DEPTH == 0 ? 0.5f : (DEPTH == 1 ? 0.38729833462074170f : 0.35355339059327379f)) * DESCALE;
-    constexpr float C1E = (DEPTH == 1 ? 0.86602540378443865f : 0.5f) * DESCALE;
-    constexpr float C0O = 0.5f * DESCALE;
+    // path coefficients sqrt((2 l_out + 1) / sum of mul_in1 over the paths into the same output block)
+    constexpr float C0E = DEPTH == 0 ? 0.28867513459481287f : 0.25f;
+    constexpr float C1O = DEPTH == 0 ? 0.5f : (DEPTH == 1 ? 0.38729833462074170f : 0.35355339059327379f);
+    constexpr float C1E = DEPTH == 1 ? 0.86602540378443865f : 0.5f;
+    constexpr float C0O = 0.5f;
 
     for (int n = blockIdx.x * MF_WAVES + wave; n < a.n_recv; n += gridDim.x * MF_WAVES) {      // wave-uniform
         const int e0 = __builtin_amdgcn_readfirstlane(a.ptr[n]), e1 = __builtin_amdgcn_readfirstlane(a.ptr[n + 1]);
@@ -256,15 +287,24 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                     float acc = emb3_b[o];
 #pragma unroll
                     for (int k = 0; k < NS; ++k) acc = fmaf(h1[k], emb3_w[o * NS + k], acc);
-                    in48[o] = S_IN * acc;
+                    in48[o] = acc;
                 }
             }
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                in48[12 + k] = S_IN * (a.attr_recv_first ? hr[k] : x0[k]);
-                in48[24 + k] = S_IN * (a.attr_recv_first ? x0[k] : hr[k]);
+                in48[12 + k] = a.attr_recv_first ? hr[k] : x0[k];
+                in48[24 + k] = a.attr_recv_first ? x0[k] : hr[k];
             }
-            in48[36] = S_IN;
+            float s_in;                                                     // this edge's input scale (the same in both halves)
+            {
+                float m = 1.0f;                                             // the bias slot's 1
+#pragma unroll
+                for (int k = 0; k < 36; ++k) m = fmaxf(m, fabsf(in48[k]));
+                s_in = pow2_scale(m, 3);
+#pragma unroll
+                for (int k = 0; k < 36; ++k) in48[k] *= s_in;
+            }
+            in48[36] = s_in;
 #pragma unroll
             for (int k = 37; k < 48; ++k) in48[k] = 0.f;
 
@@ -280,26 +320,36 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                 mfma3(H0, A0 + ks * 128 + lane, bhi, blo);
                 mfma3(H1, A0 + (3 + ks) * 128 + lane, bhi, blo);
             }
-            // ReLU, rescale (H = S_IN S_W pre-activation -> S_IN relu), split: the B operand of fc.3, k-slot q = 8 ks + j
+            // ReLU, rescale (H = s_in S_W0 pre-activation), the edge's hidden scale, split: the B operand of fc.3, k-slot
+            // q = 8 ks + j
             f16x8 hhi[3], hlo[3];
+            float s_hid;
             {
-                constexpr float RS = 1.0f / S_W;
+                const float rs = 1.0f / (s_in * S_W0);                      // a power of two
+                float m = 1.0f;                                             // the bias slot's 1
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { H0[j] = rs * fmaxf(H0[j], 0.f); m = fmaxf(m, H0[j]); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { H1[j] = h ? 0.f : rs * fmaxf(H1[j], 0.f); m = fmaxf(m, H1[j]); }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));                        // the other half holds the rest of this edge's units
+                s_hid = pow2_scale(m, 3);
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = RS * fmaxf(H0[j], 0.f);
+                for (int j = 0; j < 8; ++j) v[j] = s_hid * H0[j];
                 split8(v, hhi[0], hlo[0]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = RS * fmaxf(H0[8 + j], 0.f);
+                for (int j = 0; j < 8; ++j) v[j] = s_hid * H0[8 + j];
                 split8(v, hhi[1], hlo[1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = h ? (j == 0 ? S_IN : 0.f) : RS * fmaxf(H1[j], 0.f);
+                for (int j = 0; j < 4; ++j) v[j] = h ? (j == 0 ? s_hid : 0.f) : s_hid * H1[j];
 #pragma unroll
                 for (int j = 4; j < 8; ++j) v[j] = 0.f;
                 split8(v, hhi[2], hlo[2]);
             }
 
-            // ---- inputs of the paths (zero for a lane without an edge: its weights then multiply nothing)
-            const float lv = live ? 1.0f : 0.f;
+            // ---- inputs of the paths, times fc.3's descale - or zero for a lane without an edge: its weights then
+            // multiply nothing
+            const float lv = live ? 1.0f / (s_hid * S_W3) : 0.f;
             float p0[NS];
 #pragma unroll
             for (int u = 0; u < NS; ++u) p0[u] = lv * x0[u];
@@ -480,7 +530,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
 template <int DEPTH>
 void launch(const codlad_tp_conv_args &a, hipStream_t st) {
     constexpr int NT = DEPTH == 0 ? 8 : (DEPTH == 1 ? 11 : 13);
-    const size_t lds = (size_t)(NT + 2) * 3 * 128 * sizeof(u32x4) + MF_WAVES * 48 * sizeof(float);
+    const size_t lds = (size_t)(NT + 2) * 3 * 128 * sizeof(u32x4) + (MF_WAVES * 48 + 2 + 2 * MF_WAVES) * sizeof(float);
     static bool raised = false;
     if (!raised) {
         set_max_lds(reinterpret_cast<const void *>(tp_conv_mfma_kernel<DEPTH>), lds);

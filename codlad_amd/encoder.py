@@ -23,23 +23,31 @@ def _width(depth):
     return 12 * (depth + 1)
 
 
-def csr_by_receiver(recv, snd, n_recv):
-    """Edges (recv[e] <- snd[e]) -> (ptr int32 [n_recv + 1], snd int32 [E]) grouped by receiver, original order kept
-    inside a group (the order the reference's scatter visits them)."""
-    order = torch.sort(recv, stable=True).indices
-    counts = torch.bincount(recv, minlength=n_recv)
-    ptr = torch.zeros(n_recv + 1, dtype=torch.int32, device=recv.device)
-    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return ptr, snd[order].to(torch.int32).contiguous()
+def receiver_csr(pairs, n, mode=0):
+    """Pair list int64 [E, 2] on the GPU -> (ptr int32 [n + 1], snd int32 [<= 2 E]) of the receivers, one
+    `codlad_receiver_csr` call, no host synchronisation.  mode 0: the reference's make_directed (gcn_nn.py:54-64: edge
+    (a, b) = receiver a, sender b, reversed edges added unless the list already runs both ways); mode 1: directed as
+    given.  Senders ascending inside a receiver."""
+    pairs = pairs.to(torch.int64).contiguous()
+    E = int(pairs.shape[0])
+    dev = pairs.device
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    snd = torch.zeros(max(2 * E, 1), dtype=torch.int32, device=dev)
+    if E == 0:
+        return ptr, snd
+    work = torch.empty(2 * n + 2 + 2 * E, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().codlad_receiver_csr(_lib.ptr(pairs), E, n, mode, _lib.ptr(ptr), _lib.ptr(snd), _lib.ptr(work),
+                                             _lib.stream_ptr(dev)), "codlad_receiver_csr")
+    return ptr, snd
 
 
 def directed_csr(pairs, n):
-    """Undirected pair list [E, 2] -> receivers' CSR of the directed graph (reference gcn_nn.make_directed :54-64:
-    edge (a, b) = receiver a, sender b)."""
-    gtr_ij = bool((pairs[:, 0] > pairs[:, 1]).any())
-    gtr_ji = bool((pairs[:, 1] > pairs[:, 0]).any())
-    d = pairs if (gtr_ij and gtr_ji) else torch.cat([pairs, pairs.flip(1)], dim=0)
-    return csr_by_receiver(d[:, 0], d[:, 1], n)
+    return receiver_csr(pairs, n, 0)
+
+
+def csr_by_receiver(recv, snd, n_recv):
+    """Edges (recv[e] <- snd[e]) -> receivers' CSR."""
+    return receiver_csr(torch.stack([recv.to(torch.int64), snd.to(torch.int64)], dim=1), n_recv, 1)
 
 
 class ConvWeights:

@@ -318,6 +318,15 @@ typedef struct {
 int codlad_tp_conv(const codlad_tp_conv_args *args, void *stream);
 int codlad_tp_conv_args_size(void);      /* sizeof(codlad_tp_conv_args), for bindings to check their layout */
 
+/* The receivers' CSR codlad_tp_conv reads, from a pair list (int64 [n_pairs][2], node indices < n_nodes; what the reference's
+ * make_directed, models/gcn_nn.py:54-64, and its scatter do on the host).  mode 0: edge (a, b) = receiver a, sender b, and -
+ * unless the list already holds pairs with a > b AND pairs with b > a - the reversed edges as well (make_directed's rule);
+ * mode 1: the list is directed as given.  ptr int32 [n_nodes + 1], snd int32 [2 n_pairs] (ptr[n_nodes] entries used), senders
+ * ascending inside a receiver (a fixed order: results do not depend on the atomics).  work: int32 [2 n_nodes + 2 + 2 n_pairs].
+ * Node indices are not range-checked on the device: the caller guarantees 0 <= index < n_nodes. */
+int codlad_receiver_csr(const int64_t *pairs, int n_pairs, int n_nodes, int mode, int32_t *ptr, int32_t *snd, int32_t *work,
+                        void *stream);
+
 /* y[i] = W2 act(W1 x[i] + b1) + b2 (hidden <= 36; hidden 0: y = W2 x + b2), act 0 tanh / 1 relu, in_dim 84 / 48 / 36,
  * out_dim <= 36; mode 1: y = 1e-9 + exp(y / 2) (the prior's H_sigma, vae_model.py:263-265). */
 int codlad_mlp_rows(const float *x, int n, int in_dim, const float *w1, const float *b1, int hidden, const float *w2,

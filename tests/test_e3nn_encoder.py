@@ -225,6 +225,37 @@ def test_hip_encoder_matches_oracle(L, frames):
 
 
 @pytest.mark.gpu
+def test_receiver_csr_kernel():
+    """codlad_receiver_csr against the reference's make_directed + a stable grouping by receiver (gcn_nn.py:54-64)."""
+    from codlad_amd.encoder import receiver_csr
+    g = torch.Generator().manual_seed(4)
+    n = 700
+    x = torch.randn(n, 3, generator=g) * 6
+    und = synth.cg_nbr_list(x, 5.0)                                  # j > i, row-major
+    assert und.shape[0] > 2000
+
+    def expect(pairs, both):
+        d = torch.cat([pairs, pairs.flip(1)], 0) if both else pairs
+        return [sorted(d[d[:, 0] == a, 1].tolist()) for a in range(n)]
+
+    cases_ = [(und, 0, True), (torch.cat([und, und.flip(1)], 0), 0, False), (und.flip(1), 0, True), (und, 1, False),
+              (torch.stack([torch.randint(0, 50, (n,), generator=g), torch.arange(n)], 1), 1, False),
+              (torch.tensor([[3, 5]]), 0, True)]
+    for pairs, mode, both in cases_:
+        ptr, snd = receiver_csr(pairs.to(DEV), n, mode)
+        ptr, snd = ptr.cpu(), snd.cpu()
+        want = expect(pairs, both)
+        assert ptr[0] == 0 and int(ptr[-1]) == sum(len(w) for w in want)
+        for a in range(n):
+            assert snd[ptr[a]:ptr[a + 1]].tolist() == want[a], a
+    # a node with more than 64 neighbours, and determinism of the whole thing
+    star = torch.stack([torch.zeros(300, dtype=torch.int64), torch.arange(1, 301)], 1)
+    p1, s1 = receiver_csr(star.to(DEV), 301, 0)
+    p2, s2 = receiver_csr(star.to(DEV), 301, 0)
+    assert torch.equal(p1, p2) and torch.equal(s1, s2) and s1[:300].tolist() == list(range(1, 301))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("scale", [1.0, 30.0, 1.0 / 30.0])
 def test_tp_conv_variants_and_weight_magnitudes(variant, scale):
