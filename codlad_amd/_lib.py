@@ -71,7 +71,8 @@ class TpConvArgs(C.Structure):
                 ("typ_snd", P), ("r_sign", C.c_float), ("smear_stop", C.c_float), ("emb0_w", P), ("emb0_b", P),
                 ("emb3_w", P), ("emb3_b", P), ("emb_in", C.c_int32), ("h_recv", P), ("d_recv", C.c_int32), ("h_snd", P),
                 ("d_snd", C.c_int32), ("attr_recv_first", C.c_int32), ("fc0_w", P), ("fc0_b", P), ("fc3_w", P),
-                ("fc3_b", P), ("depth", C.c_int32), ("out", P), ("accumulate", C.c_int32), ("group", C.c_int32)]
+                ("fc3_b", P), ("depth", C.c_int32), ("out", P), ("accumulate", C.c_int32), ("group", C.c_int32),
+                ("packed", P)]
 
 
 class XyzGroup(C.Structure):
@@ -115,6 +116,8 @@ _SIGS = {
     "codlad_ic_to_xyz": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "codlad_ic_to_xyz_groups": (C.c_int, [P, C.c_int, C.c_int, P]),
     "codlad_xyz_to_ic": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int, P, P]),
+    "codlad_tp_conv_image_bytes": (C.c_int, [C.c_int]),
+    "codlad_tp_conv_pack": (C.c_int, [P, P, P]),
     "codlad_receiver_csr": (C.c_int, [P, C.c_int, C.c_int, C.c_int, P, P, P, P]),
     "codlad_bench_edge_launch": (C.c_int, [C.POINTER(DenoiserWeights), P, C.c_int, P, P, P,
                                            C.POINTER(Workspace), C.c_int, C.c_int, P]),

@@ -18,6 +18,8 @@
 
 int tp_conv_variant();                                                       // denoiser_kernels.hip: CODLAD_OPT_TP_CONV_VARIANT
 void launch_tp_conv_mfma(const codlad_tp_conv_args &a, hipStream_t st);      // encoder_mfma_kernel.hip
+void launch_tp_conv_pack(const codlad_tp_conv_args &a, void *image, hipStream_t st);
+int tp_conv_image_bytes(int depth);
 
 namespace {
 
@@ -427,6 +429,17 @@ extern "C" int codlad_tp_conv(const codlad_tp_conv_args *a, void *stream) {
 }
 
 extern "C" int codlad_tp_conv_args_size(void) { return (int)sizeof(codlad_tp_conv_args); }
+
+extern "C" int codlad_tp_conv_image_bytes(int depth) { return depth >= 0 && depth <= 2 ? tp_conv_image_bytes(depth) : -1; }
+
+extern "C" int codlad_tp_conv_pack(const codlad_tp_conv_args *a, void *image, void *stream) {
+    CODLAD_REQUIRE(a && image, "null pointer");
+    CODLAD_REQUIRE(a->fc0_w && a->fc0_b && a->fc3_w && a->fc3_b && a->emb0_w && a->emb0_b && a->emb3_w && a->emb3_b,
+                   "null weight pointer");
+    CODLAD_REQUIRE(a->depth >= 0 && a->depth <= 2 && (a->emb_in == 14 || a->emb_in == 8), "bad depth or emb_in");
+    launch_tp_conv_pack(*a, image, (hipStream_t)stream);
+    return codlad_check_launch("codlad_tp_conv_pack");
+}
 
 extern "C" int codlad_receiver_csr(const int64_t *pairs, int n_pairs, int n_nodes, int mode, int32_t *ptr, int32_t *snd,
                                    int32_t *work, void *stream) {

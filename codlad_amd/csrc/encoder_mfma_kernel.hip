@@ -29,6 +29,12 @@
 // factor that zeroes the inputs of a lane without an edge, so it costs nothing.
 #include "encoder_common.h"
 
+// Measurement-only build switch (tools/ablate_encoder.sh; results are wrong with it): 1 = no fc.3 blocks, 2 = every lane
+// reads the receiving node's own row instead of its sender's (no gather), 3 = both.
+#ifndef CODLAD_TP_ABLATE
+#define CODLAD_TP_ABLATE 0
+#endif
+
 int num_cu();                                       // denoiser_kernels.hip
 void set_max_lds(const void *fn, size_t bytes);     // denoiser_kernels.hip
 
@@ -140,19 +146,20 @@ DEV float half_sum(float v) {                         // over the 32 lanes of a 
     return v;
 }
 
-template <int DEPTH>
-__global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_conv_args a) {
-    constexpr int NT = DEPTH == 0 ? 8 : (DEPTH == 1 ? 11 : 13);
-    constexpr int D_OUT = width_of(DEPTH + 1);
-    // [fc.3: NT blocks x 3 k-steps][hi | lo][64 lanes], then [fc.0: 2 blocks x 3 k-steps][hi | lo][64], then the waves' output rows
-    extern __shared__ __align__(16) u32x4 lds[];
-    u32x4 *A3 = lds, *A0 = lds + NT * 3 * 128;
-    float *out_sh = reinterpret_cast<float *>(lds + (NT + 2) * 3 * 128);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
+// The kernel's read-only LDS image: [fc.3: NT blocks x 3 k-steps][hi | lo][64 lanes] | [fc.0: 2 blocks x 3 k-steps][hi | lo][64] |
+// scales (fc.3, fc.0, 0, 0) | edge-embedding rows (emb0: 12 x 12, emb3: 12 x 16).
+__host__ __device__ constexpr int tiles_of(int depth) { return depth == 0 ? 8 : (depth == 1 ? 11 : 13); }
+__host__ __device__ constexpr int image_bytes(int depth) { return (tiles_of(depth) + 2) * 3 * 128 * 16 + (4 + 12 * 12 + 12 * 16) * 4; }
 
-    // ---- the weight matrices' scales (largest |w| or |b| of fc.3 over the rows this depth uses, of fc.0), once per workgroup
-    float *scales = out_sh + MF_WAVES * 48;                    // [0] fc.3, [1] fc.0, then the waves' partial maxima
+// Built by one workgroup of 64 MF_WAVES threads into `img` (LDS or global memory); `red`: 2 MF_WAVES floats of LDS.
+template <int DEPTH>
+DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
+    constexpr int NT = tiles_of(DEPTH);
+    u32x4 *A3 = img, *A0 = img + NT * 3 * 128;
+    float *scales = reinterpret_cast<float *>(img + (NT + 2) * 3 * 128);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the weight matrices' scales (largest |w| or |b| of fc.3 over the rows this depth uses, of fc.0)
+    float S_W3, S_W0;
     {
         constexpr int N3 = DEPTH == 0 ? 192 : (DEPTH == 1 ? 288 : 384);
         float m3 = 0.f, m0 = 0.f;
@@ -165,17 +172,30 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
             m3 = fmaxf(m3, __shfl_xor(m3, m, 64));
             m0 = fmaxf(m0, __shfl_xor(m0, m, 64));
         }
-        if (lane == 0) { scales[2 + 2 * wave] = m3; scales[3 + 2 * wave] = m0; }
+        if (lane == 0) { red[2 * wave] = m3; red[2 * wave + 1] = m0; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 0; w < MF_WAVES; ++w) { m3 = fmaxf(m3, scales[2 + 2 * w]); m0 = fmaxf(m0, scales[3 + 2 * w]); }
-            scales[0] = pow2_scale(m3, 8);
-            scales[1] = pow2_scale(m0, 8);
-        }
-        __syncthreads();
+        for (int w = 0; w < MF_WAVES; ++w) { m3 = fmaxf(m3, red[2 * w]); m0 = fmaxf(m0, red[2 * w + 1]); }
+        S_W3 = pow2_scale(m3, 8);
+        S_W0 = pow2_scale(m0, 8);
     }
-    const float S_W3 = scales[0], S_W0 = scales[1];
-    // ---- pack the weights, once per workgroup: fragment (block, k-step) of lane l = row (l & 31), k-slots 8 (l >> 5) + 0..7
+    if (threadIdx.x < 4) scales[threadIdx.x] = threadIdx.x == 0 ? S_W3 : (threadIdx.x == 1 ? S_W0 : 0.f);
+    {
+        // emb0 rows: [w(type recv), w(type snd), w(smearing 0..7), bias, 0]  (12 floats), emb3 rows: [w 0..11, bias, 0 0 0] (16)
+        float *e0 = scales + 4, *e3 = e0 + 12 * 12;
+        for (int i = threadIdx.x; i < 12 * 12; i += 64 * MF_WAVES) {
+            const int o = i / 12, k = i % 12;
+            float v = 0.f;
+            if (k < 2) v = a.emb_in == 14 ? a.emb0_w[o * 14 + k] : 0.f;
+            else if (k < 10) v = a.emb_in == 14 ? a.emb0_w[o * 14 + 4 + k] : a.emb0_w[o * 8 + (k - 2)];
+            else if (k == 10) v = a.emb0_b[o];
+            e0[i] = v;
+        }
+        for (int i = threadIdx.x; i < 12 * 16; i += 64 * MF_WAVES) {
+            const int o = i / 16, k = i % 16;
+            e3[i] = k < 12 ? a.emb3_w[o * NS + k] : (k == 12 ? a.emb3_b[o] : 0.f);
+        }
+    }
+    // fragment (block, k-step) of lane l = row (l & 31), k-slots 8 (l >> 5) + 0..7
     for (int f = threadIdx.x; f < (NT + 2) * 3 * 64; f += 64 * MF_WAVES) {
         const int l = f & 63, blk = (f >> 6) / 3, ks = (f >> 6) % 3;
         const int row = l & 31, hb = l >> 5;
@@ -202,9 +222,40 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
             store_frag(A0 + ((blk - NT) * 3 + ks) * 128 + l, v);
         }
     }
-    __syncthreads();
+}
 
-    kfloat_p emb0_w = uni(a.emb0_w), emb0_b = uni(a.emb0_b), emb3_w = uni(a.emb3_w), emb3_b = uni(a.emb3_b);
+template <int DEPTH>
+__global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_pack_kernel(codlad_tp_conv_args a, u32x4 *img) {
+    __shared__ float red[2 * MF_WAVES];
+    build_image<DEPTH>(a, img, red);
+}
+
+template <int DEPTH>
+__global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_conv_args a) {
+    constexpr int NT = tiles_of(DEPTH);
+    constexpr int D_OUT = width_of(DEPTH + 1);
+    // the read-only image (build_image), then the waves' output rows (48 floats each) and 2 MF_WAVES floats for build_image
+    extern __shared__ __align__(16) u32x4 lds[];
+    const u32x4 *A3 = lds, *A0 = lds + NT * 3 * 128;
+    float *out_sh = reinterpret_cast<float *>(lds + image_bytes(DEPTH) / 16);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    // ---- the read-only image: packed here by every workgroup, or copied when the caller packed it once (a.packed)
+    if (a.packed) {
+        const u32x4 *src = static_cast<const u32x4 *>(a.packed);
+        for (int i = threadIdx.x; i < image_bytes(DEPTH) / 16; i += 64 * MF_WAVES) lds[i] = src[i];
+    } else {
+        build_image<DEPTH>(a, lds, out_sh + MF_WAVES * 48);
+    }
+    __syncthreads();
+    const float *scales = reinterpret_cast<const float *>(lds + (NT + 2) * 3 * 128);
+
+    // the edge-embedding MLP's weights, read back as wave-uniform (broadcast) 16-byte LDS reads: through the scalar cache
+    // every output row cost a round trip per step with nothing to overlap it
+    //   emb0 rows: [w(type recv), w(type snd), w(smearing 0..7), bias, 0]  (12 floats), emb3 rows: [w 0..11, bias, 0 0 0] (16)
+    const float S_W3 = scales[0], S_W0 = scales[1];
+    const float *e0w = scales + 4, *e3w = e0w + 12 * 12;     // 16-byte aligned
     const float step = a.smear_stop / 7.0f, coeff = -0.5f / (step * step);
     float *my_out = out_sh + wave * 48;
     // path coefficients sqrt((2 l_out + 1) / sum of mul_in1 over the paths into the same output block)
@@ -231,7 +282,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
 
         for (int base = e0; base < e1; base += 32) {
             const bool live = base + c < e1;
-            const int s = live ? a.snd[base + c] : a.snd[e0];
+            const int s = (CODLAD_TP_ABLATE & 2) ? 0 : (live ? a.snd[base + c] : a.snd[e0]);
             // geometry: r = sign (x_snd - x_recv), |r|, Y(r / |r|)
             const float rx = a.r_sign * (a.xyz_snd[3 * s] - xr), ry = a.r_sign * (a.xyz_snd[3 * s + 1] - yr),
                         rz = a.r_sign * (a.xyz_snd[3 * s + 2] - zr);
@@ -262,31 +313,23 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                     sm[k] = expf(coeff * t * t);
                 }
                 float h1[NS];
-                if (a.emb_in == 14) {                                       // [z_recv, z_snd, 0 0 0 0, smearing]
-                    const float typ_s = a.typ_snd[s];
+                const float typ_s = a.emb_in == 14 ? a.typ_snd[s] : 0.f;   // [z_recv, z_snd, 0 0 0 0, smearing] or the smearing alone
 #pragma unroll
-                    for (int o = 0; o < NS; ++o) {
-                        float acc = emb0_b[o];
-                        acc = fmaf(typ_r, emb0_w[o * 14], acc);
-                        acc = fmaf(typ_s, emb0_w[o * 14 + 1], acc);
+                for (int o = 0; o < NS; ++o) {
+                    const float *w = e0w + o * 12;
+                    float acc = w[10];
+                    acc = fmaf(typ_r, w[0], acc);
+                    acc = fmaf(typ_s, w[1], acc);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) acc = fmaf(sm[k], emb0_w[o * 14 + 6 + k], acc);
-                        h1[o] = fmaxf(acc, 0.f);
-                    }
-                } else {
-#pragma unroll
-                    for (int o = 0; o < NS; ++o) {
-                        float acc = emb0_b[o];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc = fmaf(sm[k], emb0_w[o * 8 + k], acc);
-                        h1[o] = fmaxf(acc, 0.f);
-                    }
+                    for (int k = 0; k < 8; ++k) acc = fmaf(sm[k], w[2 + k], acc);
+                    h1[o] = fmaxf(acc, 0.f);
                 }
 #pragma unroll
                 for (int o = 0; o < NS; ++o) {
-                    float acc = emb3_b[o];
+                    const float *w = e3w + o * 16;
+                    float acc = w[12];
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) acc = fmaf(h1[k], emb3_w[o * NS + k], acc);
+                    for (int k = 0; k < NS; ++k) acc = fmaf(h1[k], w[k], acc);
                     in48[o] = acc;
                 }
             }
@@ -362,15 +405,19 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
             }
 
             // ---- fc.3 block by block, each contracted at once with the inputs next to it
+            // (one block's fragments and results in flight at a time: the scheduling barrier keeps the compiler from pulling
+            // more into flight than the register file holds.  Loading block t + 1's fragments during block t was tried: no gain -
+            // the step is not waiting on LDS - and, with the loads landing in the registers the preceding matrix instruction
+            // still reads, results that changed from run to run; tools/ablate_encoder.sh has the measurements' recipe.)
             auto block = [&](int t) {
-                __builtin_amdgcn_sched_barrier(0);          // one block's fragments and results in flight at a time
+                __builtin_amdgcn_sched_barrier(0);
                 f32x16 D = zero16();
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) mfma3(D, A3 + (t * 3 + ks) * 128 + lane, hhi[ks], hlo[ks]);
                 return D;
             };
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {                                   // 12x0e
+            for (int t = 0; t < ((CODLAD_TP_ABLATE & 1) ? 0 : 6); ++t) {     // 12x0e
                 const f32x16 D = block(t);
                 float r = 0.f;
 #pragma unroll
@@ -382,7 +429,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                 s0e[t] += r;
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {                                   // 4x1o: scalars x Y1, vectors
+            for (int t = 0; t < ((CODLAD_TP_ABLATE & 1) ? 0 : 2); ++t) {     // 4x1o: scalars x Y1, vectors
                 const f32x16 D = block(6 + t);
                 float sc = 0.f;
 #pragma unroll
@@ -398,7 +445,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                 }
                 s1o[t].x += r.x; s1o[t].y += r.y; s1o[t].z += r.z;
             }
-            if (DEPTH >= 1) {
+            if (DEPTH >= 1 && !(CODLAD_TP_ABLATE & 1)) {
                 if (DEPTH >= 2) {                                           // the second vector block is first needed here
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -459,7 +506,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
                     s1e[t].x += r.x; s1e[t].y += r.y; s1e[t].z += r.z;
                 }
             }
-            if (DEPTH >= 2) {
+            if (DEPTH >= 2 && !(CODLAD_TP_ABLATE & 1)) {
                 float d9[NV];
 #pragma unroll
                 for (int u = 0; u < NV; ++u) d9[u] = dot3(v2[u], y1);
@@ -529,8 +576,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
 
 template <int DEPTH>
 void launch(const codlad_tp_conv_args &a, hipStream_t st) {
-    constexpr int NT = DEPTH == 0 ? 8 : (DEPTH == 1 ? 11 : 13);
-    const size_t lds = (size_t)(NT + 2) * 3 * 128 * sizeof(u32x4) + (MF_WAVES * 48 + 2 + 2 * MF_WAVES) * sizeof(float);
+    const size_t lds = (size_t)image_bytes(DEPTH) + (MF_WAVES * 48 + 2 * MF_WAVES) * sizeof(float);
     static bool raised = false;
     if (!raised) {
         set_max_lds(reinterpret_cast<const void *>(tp_conv_mfma_kernel<DEPTH>), lds);
@@ -547,4 +593,13 @@ void launch_tp_conv_mfma(const codlad_tp_conv_args &a, hipStream_t st) {
     if (a.depth == 0) launch<0>(a, st);
     else if (a.depth == 1) launch<1>(a, st);
     else launch<2>(a, st);
+}
+
+int tp_conv_image_bytes(int depth) { return image_bytes(depth); }
+
+void launch_tp_conv_pack(const codlad_tp_conv_args &a, void *image, hipStream_t st) {
+    u32x4 *img = static_cast<u32x4 *>(image);
+    if (a.depth == 0) hipLaunchKernelGGL((tp_conv_pack_kernel<0>), dim3(1), dim3(64 * MF_WAVES), 0, st, a, img);
+    else if (a.depth == 1) hipLaunchKernelGGL((tp_conv_pack_kernel<1>), dim3(1), dim3(64 * MF_WAVES), 0, st, a, img);
+    else hipLaunchKernelGGL((tp_conv_pack_kernel<2>), dim3(1), dim3(64 * MF_WAVES), 0, st, a, img);
 }

@@ -81,6 +81,8 @@ class _Stack:
         self.lib = _lib.lib()
         assert C.sizeof(_lib.TpConvArgs) == self.lib.codlad_tp_conv_args_size()
         self.w = ConvWeights(state_dict, self.device)
+        self._images = {}          # (layer, depth, embedding, emb_in) -> the layer's packed weight image (codlad_tp_conv_pack)
+        self.pack_weights = True   # False: every workgroup of every launch packs the image itself (same bits, slower)
 
     def conv(self, layer, depth, csr, xyz_recv, xyz_snd, typ_recv, typ_snd, r_sign, smear_stop, emb, emb_in, h_recv,
              h_snd, recv_first, out, accumulate, group):
@@ -100,6 +102,12 @@ class _Stack:
         a.fc0_w, a.fc0_b = self.w.p(layer + ".fc.0.weight"), self.w.p(layer + ".fc.0.bias")
         a.fc3_w, a.fc3_b = self.w.p(layer + ".fc.3.weight"), self.w.p(layer + ".fc.3.bias")
         a.depth, a.out, a.accumulate, a.group = depth, _lib.ptr(out), int(accumulate), group
+        key = (layer, depth, emb, emb_in)
+        if self.pack_weights and key not in self._images:                       # once per layer: the weights as the matrix-pipe kernel holds them in LDS
+            img = torch.empty(self.lib.codlad_tp_conv_image_bytes(depth), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.codlad_tp_conv_pack(C.byref(a), _lib.ptr(img), _lib.stream_ptr(self.device)), "codlad_tp_conv_pack")
+            self._images[key] = img
+        a.packed = _lib.ptr(self._images[key]) if self.pack_weights else None
         _lib.check(self.lib.codlad_tp_conv(C.byref(a), _lib.stream_ptr(self.device)), "codlad_tp_conv")
 
     def embed(self, name, idx):

@@ -314,9 +314,17 @@ typedef struct {
     int32_t depth;                         /* 0, 1, 2 */
     float *out;
     int32_t accumulate, group;
+    const void *packed;                    /* NULL, or the layer's weights as codlad_tp_conv_pack left them (below) */
 } codlad_tp_conv_args;
 int codlad_tp_conv(const codlad_tp_conv_args *args, void *stream);
 int codlad_tp_conv_args_size(void);      /* sizeof(codlad_tp_conv_args), for bindings to check their layout */
+/* The matrix-pipe kernel keeps a layer's weights (fc.0, fc.3, the edge embedding) in LDS as split-fp16 operand fragments.
+ * With packed == NULL every workgroup of every launch builds that image from the fp32 weights (18-35 us, most of a small
+ * graph's launch); codlad_tp_conv_pack builds it ONCE into `image` (codlad_tp_conv_image_bytes(depth) bytes of device
+ * memory, 16-byte aligned) from the weight pointers, depth and emb_in of `args` (graph fields are not read), and launches that
+ * pass it as `packed` copy it.  The image depends on nothing else; results are bit-identical either way. */
+int codlad_tp_conv_image_bytes(int depth);
+int codlad_tp_conv_pack(const codlad_tp_conv_args *args, void *image, void *stream);
 
 /* The receivers' CSR codlad_tp_conv reads, from a pair list (int64 [n_pairs][2], node indices < n_nodes; what the reference's
  * make_directed, models/gcn_nn.py:54-64, and its scatter do on the host).  mode 0: edge (a, b) = receiver a, sender b, and -

@@ -197,8 +197,11 @@ def test_hip_prior_matches_oracle(weights, L):
     batch = synth.make_batch(synth.make_protein(L, 40 + L, n_frames=2))
     cg_z, cg_xyz, nbr = batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:], batch["CG_nbr_list"]
     mu_ref, sg_ref = e3.prior_forward(sd, cg_z, cg_xyz, nbr)
-    mu, sg = Prior(sd, DEV).forward(cg_z, cg_xyz, nbr)
+    prior = Prior(sd, DEV)
+    mu, sg = prior.forward(cg_z, cg_xyz, nbr)
     assert rel_err(mu, mu_ref) < 1e-5 and rel_err(sg, sg_ref) < 1e-5
+    mu2, sg2 = prior.forward(cg_z, cg_xyz, nbr)                    # beads with > 64 neighbours at L = 129: several steps per node
+    assert torch.equal(mu, mu2) and torch.equal(sg, sg2)
 
 
 @pytest.mark.gpu
@@ -215,6 +218,10 @@ def test_hip_encoder_matches_oracle(L, frames):
     got = Encoder(sd, DEV).forward(*args)
     assert got.shape == ref.shape == (L * frames, 36)
     assert rel_err(got, ref) < 1e-5
+    # the weights packed once per layer (codlad_tp_conv_pack) or by every workgroup: the same bits
+    unpacked = Encoder(sd, DEV)
+    unpacked.pack_weights = False
+    assert torch.equal(unpacked.forward(*args), got)
     # a frame's latent does not depend on what shares the batch
     if frames == 2:
         one = synth.make_atoms(prot, frame_ids=[1], seed=L)
