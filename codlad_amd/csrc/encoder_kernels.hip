@@ -337,18 +337,22 @@ __global__ void embed_rows_kernel(const float *table, const int *idx, int n, int
 // Receivers' CSR of a pair list (the reference's make_directed + the grouping its scatter does, models/gcn_nn.py:54-64):
 // histogram -> scan -> fill -> per-receiver sort by sender, so that the edge order inside a receiver (and with it the
 // rounding of its mean) is a function of the graph alone, not of the atomics' arrival order.
-//   work: degA [n] | degB [n] | flags [2] | tmp [2 E]
+//   work: degA [n] | degB [n] | flags [2] | tmp [2 E] | slot [2 E]
+// (the counting pass keeps what its atomics return - an edge's slot inside its receiver's group - so the fill pass needs
+// no atomics of its own)
 __global__ void csr_hist_kernel(const int64_t *pairs, int E, int n, int *work) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int a = (int)pairs[2 * (size_t)e], b = (int)pairs[2 * (size_t)e + 1];
-    atomicAdd(work + a, 1);
-    atomicAdd(work + n + b, 1);
+    int *slot = work + 2 * n + 2 + 2 * (size_t)E;
+    slot[e] = atomicAdd(work + a, 1);
+    slot[E + e] = atomicAdd(work + n + b, 1);
     if (a > b) work[2 * n] = 1;            // benign race: every writer stores 1
     if (b > a) work[2 * n + 1] = 1;
 }
 
-// one workgroup: ptr = exclusive scan of degA (+ degB when the list holds one direction only); degA becomes the fill cursor
+// one workgroup: ptr = exclusive scan of degA (+ degB when the list holds one direction only); degA keeps every receiver's
+// number of edges of the first kind (the second kind's slots start behind them)
 __global__ __launch_bounds__(1024) void csr_scan_kernel(int n, int mode, int *work, int *ptr) {
     __shared__ int part[1024];
     const int both = mode == 0 && !(work[2 * n] && work[2 * n + 1]);
@@ -365,22 +369,22 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int n, int mode, int *wo
     }
     int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
     for (int i = lo; i < hi; ++i) {
-        const int d = work[i] + (both ? work[n + i] : 0);
         ptr[i] = run;
-        work[i] = run;
-        run += d;
+        run += work[i] + (both ? work[n + i] : 0);
     }
     if (threadIdx.x == 1023) ptr[n] = part[1023];
+    __syncthreads();                                            // every thread has read the flags
     if (threadIdx.x == 0) work[2 * n] = both;                   // the fill reads the decision from here
 }
 
-__global__ void csr_fill_kernel(const int64_t *pairs, int E, int n, int *work) {
+__global__ void csr_fill_kernel(const int64_t *pairs, int E, int n, const int *ptr, int *work) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int a = (int)pairs[2 * (size_t)e], b = (int)pairs[2 * (size_t)e + 1];
     int *tmp = work + 2 * n + 2;
-    tmp[atomicAdd(work + a, 1)] = b;
-    if (work[2 * n]) tmp[atomicAdd(work + b, 1)] = a;
+    const int *slot = tmp + 2 * (size_t)E;
+    tmp[ptr[a] + slot[e]] = b;
+    if (work[2 * n]) tmp[ptr[b] + work[b] + slot[E + e]] = a;
 }
 
 // one wave per receiver: senders ascending (rank sort; equal senders keep their slots' order)
@@ -451,7 +455,7 @@ extern "C" int codlad_receiver_csr(const int64_t *pairs, int n_pairs, int n_node
     const dim3 per_pair((n_pairs + 255) / 256), block(256);
     hipLaunchKernelGGL(csr_hist_kernel, per_pair, block, 0, st, pairs, n_pairs, n_nodes, work);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, n_nodes, mode, work, ptr);
-    hipLaunchKernelGGL(csr_fill_kernel, per_pair, block, 0, st, pairs, n_pairs, n_nodes, work);
+    hipLaunchKernelGGL(csr_fill_kernel, per_pair, block, 0, st, pairs, n_pairs, n_nodes, ptr, work);
     hipLaunchKernelGGL(csr_sort_kernel, dim3((n_nodes + 3) / 4), block, 0, st, n_nodes, ptr, work, snd);
     return codlad_check_launch("codlad_receiver_csr");
 }

@@ -244,7 +244,18 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
     // ---- the read-only image: packed here by every workgroup, or copied when the caller packed it once (a.packed)
     if (a.packed) {
         const u32x4 *src = static_cast<const u32x4 *>(a.packed);
-        for (int i = threadIdx.x; i < image_bytes(DEPTH) / 16; i += 64 * MF_WAVES) lds[i] = src[i];
+        constexpr int N16 = image_bytes(DEPTH) / 16, PER = (N16 + 64 * MF_WAVES - 1) / (64 * MF_WAVES);
+        u32x4 v[PER];                                       // all of a thread's loads in flight, then the stores
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 64 * MF_WAVES;
+            if (i < N16) v[k] = src[i];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 64 * MF_WAVES;
+            if (i < N16) lds[i] = v[k];
+        }
     } else {
         build_image<DEPTH>(a, lds, out_sh + MF_WAVES * 48);
     }

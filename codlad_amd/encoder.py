@@ -35,7 +35,7 @@ def receiver_csr(pairs, n, mode=0):
     snd = torch.zeros(max(2 * E, 1), dtype=torch.int32, device=dev)
     if E == 0:
         return ptr, snd
-    work = torch.empty(2 * n + 2 + 2 * E, dtype=torch.int32, device=dev)
+    work = torch.empty(2 * n + 2 + 4 * E, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().codlad_receiver_csr(_lib.ptr(pairs), E, n, mode, _lib.ptr(ptr), _lib.ptr(snd), _lib.ptr(work),
                                              _lib.stream_ptr(dev)), "codlad_receiver_csr")
     return ptr, snd

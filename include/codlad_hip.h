@@ -330,7 +330,7 @@ int codlad_tp_conv_pack(const codlad_tp_conv_args *args, void *image, void *stre
  * make_directed, models/gcn_nn.py:54-64, and its scatter do on the host).  mode 0: edge (a, b) = receiver a, sender b, and -
  * unless the list already holds pairs with a > b AND pairs with b > a - the reversed edges as well (make_directed's rule);
  * mode 1: the list is directed as given.  ptr int32 [n_nodes + 1], snd int32 [2 n_pairs] (ptr[n_nodes] entries used), senders
- * ascending inside a receiver (a fixed order: results do not depend on the atomics).  work: int32 [2 n_nodes + 2 + 2 n_pairs].
+ * ascending inside a receiver (a fixed order: results do not depend on the atomics).  work: int32 [2 n_nodes + 2 + 4 n_pairs].
  * Node indices are not range-checked on the device: the caller guarantees 0 <= index < n_nodes. */
 int codlad_receiver_csr(const int64_t *pairs, int n_pairs, int n_nodes, int mode, int32_t *ptr, int32_t *snd, int32_t *work,
                         void *stream);
