@@ -37,3 +37,8 @@ rm -rf $OUT/trace5
 python3 tools/ab_variants.py DEC_EDGE_VARIANT=1 DEC_EDGE_VARIANT=0 --rounds 2 --config cfg5 > $OUT/decode_ab.txt 2>/dev/null
 python3 tools/decode_precision_probe.py > $OUT/decode_precision.txt 2>/dev/null
 echo "decode done"
+# the e3nn encoder / prior: latency, kernel stats, counters of the conv kernel on one large graph
+bash tools/profile_encoder.sh $TAG/encoder > /dev/null 2>&1
+bash tools/pmc_conv.sh $TAG/pmc_conv 2 > $OUT/encoder_pmc_conv.txt 2>&1
+cp $OUT/encoder/latency.txt $OUT/encoder_latency.txt; cp $OUT/encoder/kernel_stats.txt $OUT/encoder_kernel_stats.txt
+echo "encoder done"
