@@ -110,6 +110,8 @@ def read_pdb(path):
             name, elem = line[12:16].strip(), line[76:78].strip()
             if elem.upper() in ("H", "D") or (not elem and name.lstrip("0123456789")[:1] == "H"):
                 continue
+            if line[16] not in (" ", "A"):                  # alternate locations: the first one only
+                continue
             if first:
                 k = (line[21], line[22:27])
                 if k != key:
