@@ -1,7 +1,8 @@
 """Drop-in for the two pieces of the reference's utils/dataset_module.py the hot path touches:
 `get_norm_feature` (latent (de-)normalisation, dataset_module.py:230-256) and `CG_collate`'s batch
 schema (dataset_module.py:259-295), plus `load_dataset` (dataset_module.py:144-225) for multi-model PDB files, built on
-utils/dataset_builder.py instead of mdtraj (the .xtc branch, `single=False`, is not built: no reader for that format)."""
+utils/dataset_builder.py and utils/xtc.py instead of mdtraj (the .xtc reader is a restatement of the published format with
+no third-party file to check it against: parity unpinned)."""
 import os
 
 import numpy as np
@@ -67,7 +68,8 @@ def CG_collate(dicts):
 
 
 def load_dataset(data_path, params, single=True, device="cuda"):
-    """dataset_module.py:144-225 for `single=True`: `{data_path}.pdb` (a multi-model ensemble) -> (DataLoader of CG_collate
+    """dataset_module.py:144-225: `{data_path}.pdb` (a multi-model ensemble; `single=False`: the Atlas directory layout with
+    .xtc replicas) -> (DataLoader of CG_collate
     batches, info_dict, n_atoms, n_cgs, atomic_nums, topology of the interior residues).  `params`: the VAE's
     modelparams (atom_cutoff, cg_cutoff, edgeorder).  The reference's file-specific trimming of thirteen PED entries
     (dataset_module.py:167-179: their first and last residue dropped before anything else) is kept."""
@@ -75,9 +77,22 @@ def load_dataset(data_path, params, single=True, device="cuda"):
 
     from . import dataset_builder as db
     from .protein_module import info_from_residues
-    if not single:
-        raise NotImplementedError("load_dataset(single=False) reads .xtc trajectories; only multi-model PDB files are read here")
-    top, frames = db.read_pdb(f"{data_path}.pdb")
+    if single:
+        top, frames = db.read_pdb(f"{data_path}.pdb")
+    else:
+        # the Atlas layout (dataset_module.py:150-160): <dir>/<name>/<name>.pdb + three replica trajectories, the
+        # reference structure first, every 10 000th frame kept
+        from .xtc import read_xtc
+        name = os.path.basename(data_path)
+        top, ref = db.read_pdb(os.path.join(data_path, f"{name}.pdb"))
+        parts = [ref[:1]]
+        for r in (1, 2, 3):
+            xyz = read_xtc(os.path.join(data_path, f"{name}_prod_R{r}_fit.xtc"))[0]
+            if xyz.shape[1] != top.n_atoms:
+                raise ValueError(f"{name}_prod_R{r}_fit.xtc has {xyz.shape[1]} atoms, the topology's heavy atoms are {top.n_atoms}: "
+                                 "trajectories with hydrogens need the all-atom topology's heavy-atom selection")
+            parts.append(xyz)
+        frames = np.concatenate(parts, 0)[::10000]
     if os.path.basename(data_path) in _PED_TRIM_ENDS:
         a, b = int(top.first_atom[1]), int(top.first_atom[top.n_residues - 1])
         top, frames = top.subset_residues(1, top.n_residues - 1), frames[:, a:b]
@@ -85,7 +100,8 @@ def load_dataset(data_path, params, single=True, device="cuda"):
     testset, _mapping = db.build_split_dataset(top, frames, params, prot_idx=0, device=device)
     nfirst, nlast = len(top.atom_names[0]), len(top.atom_names[-1])
     atomic_nums = top.atomic_nums()[nfirst:top.n_atoms - nlast]
-    loader = DataLoader(testset, batch_size=min(len(testset), 96), collate_fn=CG_collate, shuffle=False, drop_last=False)
+    loader = DataLoader(testset, batch_size=min(len(testset), 96 if single else 24), collate_fn=CG_collate, shuffle=False,
+                        drop_last=False)
     return loader, {0: info}, top.n_atoms - nfirst - nlast, n_cgs, atomic_nums, top.subset_residues(1, top.n_residues - 1)
 
 

@@ -5,7 +5,8 @@
 residue names and, per residue, the atom names in file order - so the builder here takes those lists
 (`info_from_residues`), and `read_pdb_topology` extracts them from a PDB file without mdtraj.  The reference writes
 generated trajectories through mdtraj as .xtc and .pdb (test.py:787-803); `write_pdb` writes the multi-model PDB
-directly (coordinates in Angstrom as they leave `ic_to_xyz`); the compressed .xtc format is not produced.
+directly (coordinates in Angstrom as they leave `ic_to_xyz`); the compressed .xtc format is written and read by
+utils/xtc.py.
 
 The data-set builder of the same reference file (`build_ic_peptide_dataset`, `build_split_dataset`, `CGDataset`,
 `get_neighbor_list`, protein_module.py:567-951) lives in utils/dataset_builder.py and is re-exported here under the

@@ -8,7 +8,7 @@ directories of utils/model_module.py), the call sequence build_model -> create_d
 p_sample_loop -> get_norm_feature -> latent_decode -> ic_to_xyz, and the output directory.
 Different by design: all ensemble members of a batch of frames are sampled in ONE launch set (the
 reference loops over them); the C2 prior call that only supplies `mask` (test.py:495) is replaced by
-the length mask; mdtraj I/O is replaced by saving coordinates as .npy (and multi-model PDB, --save_pdb).
+the length mask; mdtraj I/O is replaced by saving coordinates as .npy (and multi-model PDB + .xtc, --save_pdb).
 Data: `--pdb_files ens.pdb ...` (multi-model PDB ensembles -> the reference's load_dataset without mdtraj),
 `--data_process --data_files f.pkl ...` (pickled per-frame dicts, as the reference's --data_process branch reads
 them) or `--synthetic` (no PED/PDB/Atlas files ship with the reference).
@@ -315,11 +315,13 @@ def main(args):
             evaluation.report(name, args)
         np.save(os.path.join(save_dir, f"{name}_xyz_recon.npy"), xyz.cpu().numpy())
         if getattr(args, "save_pdb", False) and name in _TOPOLOGY:
-            # reference test.py:787-796 writes the generated ensemble through mdtraj (.xtc + .pdb); here the multi-model
-            # PDB directly, frames of member 0 first (coordinates in Angstrom)
+            # reference test.py:787-796 writes the generated ensemble through mdtraj (.xtc + .pdb); here both directly, frames
+            # of member 0 first (multi-model PDB in Angstrom, .xtc in nm as the format has it)
             from codlad_amd.utils.protein_module import write_pdb
-            write_pdb(os.path.join(save_dir, f"generated_traj_{name}.pdb"), xyz.reshape(-1, xyz.shape[2], 3).cpu().numpy(),
-                      *_TOPOLOGY[name])
+            from codlad_amd.utils.xtc import write_xtc
+            frames = xyz.reshape(-1, xyz.shape[2], 3).cpu().numpy()
+            write_pdb(os.path.join(save_dir, f"generated_traj_{name}.pdb"), frames, *_TOPOLOGY[name])
+            write_xtc(os.path.join(save_dir, f"generated_traj_{name}.xtc"), frames)
         print(f"{name}: {B} frames x {E} members, L={L}, {xyz.shape[2]} atoms: {dt:.2f}s "
               f"({B * E / dt:.1f} structures/s)", flush=True)
     if world > 1:
@@ -375,7 +377,7 @@ if __name__ == "__main__":
     p.add_argument("--synthetic", action="store_true", help="synthetic PED/PDB/Atlas-shaped proteins")
     p.add_argument("--synthetic_frames", type=int, default=10)
     p.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (no checkpoints ship)")
-    p.add_argument("--save_pdb", action="store_true", help="also write the generated ensemble as a multi-model PDB")
+    p.add_argument("--save_pdb", action="store_true", help="also write the generated ensemble as a multi-model PDB and an .xtc trajectory")
     p.add_argument("--pdb_files", nargs="*", default=None,
                    help="multi-model PDB ensembles to build the test set from (the reference's load_dataset, without mdtraj)")
     p.add_argument("--atom_cutoff", type=float, default=9.0)

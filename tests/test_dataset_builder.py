@@ -282,4 +282,4 @@ def test_cli_recon_from_a_pdb_file(tmp_path):
     assert npy, files
     xyz = np.load(npy[0])
     assert xyz.shape[-2:] == (full.shape[1] - 2, 3) and np.isfinite(xyz).all()
-    assert any(f.endswith(".pdb") for f in files)
+    assert any(f.endswith(".pdb") for f in files) and any(f.endswith(".xtc") for f in files)
