@@ -169,7 +169,7 @@ class TensorProduct:
             w_off += m1 * m2 * mo
             w3j = wigner_3j(l1, l2, lo).to(x1.dtype)
             r = torch.einsum("euvw,eui,evj,ijk->ewk", w, a, b, w3j)
-            out[:, oo[io]:oo[io] + mo * (2 * lo + 1)] += c * r.reshape(E, -1)
+            out[:, oo[io]:oo[io] + mo * (2 * lo + 1)] += c * r.reshape(E, mo * (2 * lo + 1))
         assert w_off == self.weight_numel
         return out
 

@@ -232,6 +232,23 @@ def test_hip_encoder_matches_oracle(L, frames):
 
 
 @pytest.mark.gpu
+def test_isolated_nodes_and_empty_graphs():
+    """Receivers without a single edge (mean over nothing = 0: the node keeps its padded features) and a graph without any
+    edge at all, against the oracle."""
+    from codlad_amd.encoder import Prior
+    sd = synth.prior_state_dict(35)
+    batch = synth.make_batch(synth.make_protein(12, 77, n_frames=1))
+    cg_z, cg_xyz = batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:].clone()
+    cg_xyz[3] += 500.0                                          # one bead far from all others
+    nbr = synth.cg_nbr_list(cg_xyz, 21.0)
+    assert not ((nbr == 3).any()) and nbr.shape[0] > 10
+    for pairs in (nbr, nbr[:0]):
+        mu_ref, sg_ref = e3.prior_forward(sd, cg_z, cg_xyz, pairs)
+        mu, sg = Prior(sd, DEV).forward(cg_z, cg_xyz, pairs)
+        assert bool(torch.isfinite(mu).all()) and rel_err(mu, mu_ref) < 1e-5 and rel_err(sg, sg_ref) < 1e-5
+
+
+@pytest.mark.gpu
 def test_receiver_csr_kernel():
     """codlad_receiver_csr against the reference's make_directed + a stable grouping by receiver (gcn_nn.py:54-64)."""
     from codlad_amd.encoder import receiver_csr
