@@ -340,15 +340,29 @@ __global__ void embed_rows_kernel(const float *table, const int *idx, int n, int
 //   work: degA [n] | degB [n] | flags [2] | tmp [2 E] | slot [2 E]
 // (the counting pass keeps what its atomics return - an edge's slot inside its receiver's group - so the fill pass needs
 // no atomics of its own)
-__global__ void csr_hist_kernel(const int64_t *pairs, int E, int n, int *work) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int a = (int)pairs[2 * (size_t)e], b = (int)pairs[2 * (size_t)e + 1];
+__global__ __launch_bounds__(256) void csr_hist_kernel(const int64_t *pairs, int E, int n, int *work) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool in = e < E;
+    const int a = in ? (int)pairs[2 * (size_t)e] : -1, b = in ? (int)pairs[2 * (size_t)e + 1] : -1;
     int *slot = work + 2 * n + 2 + 2 * (size_t)E;
-    slot[e] = atomicAdd(work + a, 1);
-    slot[E + e] = atomicAdd(work + n + b, 1);
-    if (a > b) work[2 * n] = 1;            // benign race: every writer stores 1
-    if (b > a) work[2 * n + 1] = 1;
+    // first index: a pair list in torch.nonzero order has long runs of equal receivers - one atomic per run of a wave
+    // instead of one per pair on the same counter (the run's first lane adds the run's length and hands out the slots)
+    const int prev = __shfl_up(a, 1, 64);
+    const bool head = lane == 0 || prev != a;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);          // run heads at or below this lane
+    const int my_head = 63 - __builtin_clzll(below);
+    const unsigned long long above = heads & ~((2ull << my_head) - 1ull);      // the next run's head, if any
+    const int run_end = above ? __builtin_ctzll(above) : 64;
+    int base = 0;
+    if (head && in) base = atomicAdd(work + a, run_end - lane);
+    base = __shfl(base, my_head, 64);
+    if (in) {
+        slot[e] = base + (lane - my_head);
+        slot[E + e] = atomicAdd(work + n + b, 1);
+        if (a > b) work[2 * n] = 1;            // benign race: every writer stores 1
+        if (b > a) work[2 * n + 1] = 1;
+    }
 }
 
 // one workgroup: ptr = exclusive scan of degA (+ degB when the list holds one direction only); degA keeps every receiver's
@@ -387,12 +401,35 @@ __global__ void csr_fill_kernel(const int64_t *pairs, int E, int n, const int *p
     if (work[2 * n]) tmp[ptr[b] + work[b] + slot[E + e]] = a;
 }
 
-// one wave per receiver: senders ascending (rank sort; equal senders keep their slots' order)
+// one wave per receiver: senders ascending (rank sort; equal senders keep their slots' order).  Up to 256 senders sit in four
+// registers per lane and are compared through v_readlane (a loop of uniform-address loads was one L1 round trip per sender);
+// longer lists fall back to that loop.
 __global__ __launch_bounds__(256) void csr_sort_kernel(int n, const int *ptr, const int *work, int *snd) {
     const int node = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (node >= n) return;
     const int *tmp = work + 2 * n + 2;
-    const int e0 = ptr[node], deg = ptr[node + 1] - e0;
+    const int e0 = __builtin_amdgcn_readfirstlane(ptr[node]), deg = __builtin_amdgcn_readfirstlane(ptr[node + 1]) - e0;
+    if (deg <= 256) {
+        int k[4], r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            k[q] = 64 * q + lane < deg ? tmp[e0 + 64 * q + lane] : 0x7fffffff;
+            r[q] = 0;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                                       // senders 64 p .. 64 p + 63, one by one
+            const int lim = deg - 64 * p < 64 ? deg - 64 * p : 64;
+            for (int j = 0; j < lim; ++j) {                                  // j is wave-uniform
+                const int kj = __builtin_amdgcn_readlane(k[p], j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] += (kj < k[q]) || (kj == k[q] && 64 * p + j < 64 * q + lane);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (64 * q + lane < deg) snd[e0 + r[q]] = k[q];
+        return;
+    }
     for (int i = lane; i < deg; i += 64) {
         const int key = tmp[e0 + i];
         int rank = 0;
