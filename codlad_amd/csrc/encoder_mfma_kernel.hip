@@ -114,14 +114,17 @@ DEV void store_frag(u32x4 *dst, const float (&v)[8]) {     // dst[0] = the hi fr
 }
 
 DEV void split8(const float (&v)[8], f16x8 &hi, f16x8 &lo) {
+    u32x4 H, L;                                   // whole 32-bit words: element-wise inserts into f16x8 cost a v_mov / v_perm each
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         const f32x2 x = {v[j], v[j + 1]};
         const f16x2 hh = __builtin_convertvector(x, f16x2);
         const f16x2 ll = split_lo_pair(hh, x);
-        hi[j] = hh.x; hi[j + 1] = hh.y;
-        lo[j] = ll.x; lo[j + 1] = ll.y;
+        H[j >> 1] = __builtin_bit_cast(unsigned, hh);
+        L[j >> 1] = __builtin_bit_cast(unsigned, ll);
     }
+    hi = as_f16x8(H);
+    lo = as_f16x8(L);
 }
 
 DEV f32x16 zero16() {

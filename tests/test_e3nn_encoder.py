@@ -232,6 +232,49 @@ def test_hip_encoder_matches_oracle(L, frames):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_hip_conv_layer_is_equivariant_at_full_size(depth):
+    """The size-independent property on the largest graph of BASELINE's PED set (the L = 129 protein's 10 frames: ~10 700
+    atoms, ~1.1 M directed edges, too large for the oracle in a test): rotating / inverting the coordinates and the vector
+    features rotates / flips the layer's output blocks - 0e invariant, 1o a vector, 1e a pseudo-vector, 0o a pseudo-scalar -
+    to fp32 accuracy, on the matrix-pipe kernel."""
+    from codlad_amd.encoder import Encoder, directed_csr
+    enc = Encoder(synth.encoder_state_dict(36), DEV)
+    prot = synth.make_protein(129, 1003, n_frames=10)
+    atoms = synth.make_atoms(prot, seed=3)
+    xa, ta = atoms["nxyz"][:, 1:].to(DEV).contiguous(), atoms["nxyz"][:, 0].to(DEV).contiguous()
+    na = xa.shape[0]
+    csr = directed_csr(atoms["nbr_list"].to(DEV), na)
+    assert int(csr[0][-1]) > 1_000_000
+    g = torch.Generator(device=DEV).manual_seed(depth)
+    h = torch.randn(na, 12 * (depth + 1), generator=g, device=DEV)
+
+    def run(xyz_, h_):
+        out = torch.empty(na, 12 * (depth + 2), device=DEV)
+        enc.conv(f"atom_conv_layers.{depth}", depth, csr, xyz_.contiguous(), xyz_.contiguous(), ta, ta, 1.0, 14.0,
+                 "atom_edge_embedding", 14, h_.contiguous(), h_.contiguous(), True, out, False, 64)
+        return out
+
+    def act(feat, R, parity):
+        out = feat.clone()
+        if feat.shape[1] >= 24:
+            out[:, 12:24] = (feat[:, 12:24].reshape(-1, 4, 3) @ R.T).reshape(-1, 12) * parity          # 1o
+        if feat.shape[1] >= 36:
+            out[:, 24:36] = (feat[:, 24:36].reshape(-1, 4, 3) @ R.T).reshape(-1, 12)                   # 1e
+        if feat.shape[1] >= 48:
+            out[:, 36:48] = feat[:, 36:48] * parity                                                    # 0o
+        return out
+
+    base = run(xa, h)
+    assert bool(torch.isfinite(base).all())
+    scale = float(base.abs().max())
+    for R64, parity in ((_rot(21), 1.0), (_rot(22), -1.0)):
+        R = R64.float().to(DEV)
+        got = run((xa @ R.T) * parity, act(h, R, parity))
+        assert float((got - act(base, R, parity)).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.gpu
 def test_isolated_nodes_and_empty_graphs():
     """Receivers without a single edge (mean over nothing = 0: the node keeps its padded features) and a graph without any
     edge at all, against the oracle."""
