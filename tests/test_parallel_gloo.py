@@ -65,21 +65,24 @@ def _worker(rank, world, port, lengths, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_broadcast_shard_gather_world2():
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 8])
+def test_broadcast_shard_gather(world):
+    """world 8: the rank count of the node the scaling bench runs on (more ranks than some shards have units: 9 units on 8
+    ranks leaves seven ranks one unit each)."""
     lengths = [46, 87, 92, 129, 505, 39, 155, 60, 87]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, lengths, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(100)
+        p.join(200)
         assert p.exitcode == 0
-    res = sorted(q.get(timeout=5) for _ in range(2))
+    res = sorted(q.get(timeout=5) for _ in range(world))
     assert all(ok for _, ok, _ in res)
-    assert res[0][2] == res[1][2] and sum(res[0][2]) == len(lengths)
+    assert all(r[2] == res[0][2] for r in res) and sum(res[0][2]) == len(lengths)
 
 
 def _exps(w):
