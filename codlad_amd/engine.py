@@ -274,6 +274,31 @@ class Denoiser:
             self.check_status(job)
         return x
 
+    def sample_many(self, jobs, x_Ts, noises, tables, check=True):
+        """Several independent jobs at once, each on its own HIP stream: the node kernel of a 35 000-node job occupies 139 of
+        the 256 CUs and every kernel has a tail - with a second job in flight another job's edge kernels run there (two
+        half-jobs of BASELINE configuration 2: 1.03 x; more than two parts lose).  Every job carries its
+        own workspace and the library keeps no state between jobs, so the results are those of `sample` job by job."""
+        if not hasattr(self, "_streams"):
+            self._streams = []
+        while len(self._streams) < len(jobs):
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream(self.device)
+        for job in jobs:                                  # features and the step tables once, on the caller's stream
+            self._fresh_features(job.structures)
+        self.step_mods(tables.timestep_map)
+        outs = []
+        for job, x_T, noise, st in zip(jobs, x_Ts, noises, self._streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self.sample(job, x_T, noise, tables, check=False))
+        for st in self._streams[:len(jobs)]:
+            cur.wait_stream(st)
+        if check:
+            for job in jobs:
+                self.check_status(job)
+        return outs
+
     def ddpm_update(self, x, model_out, noise, tables, i, return_x_start=False):
         _require_cuda(x, "x")
         n = x.numel() // 3

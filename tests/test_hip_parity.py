@@ -307,6 +307,26 @@ def test_stepwise_equals_fused_loop(den, sd):
     assert torch.equal(x, fused)
 
 
+def test_jobs_on_separate_streams_equal_jobs_one_by_one(den):
+    """Denoiser.sample_many: independent jobs enqueued on their own HIP streams (so that one job's kernels fill the CUs
+    another's leave idle) give, job by job, the bits of `sample` - every job has its own workspace and status word."""
+    T = 10
+    tb = tables(T)
+    jobs, xs, ns = [], [], []
+    for k, name in enumerate(("L46_B2_T10", "L87_B2_T10") if "L87_B2_T10" in cases.LOOP_CASES else ("L46_B2_T10", "L46_B2_T10")):
+        L, B, seed, _T = cases.LOOP_CASES[name]
+        prot, _batch, _x, _t, _mask = cases.denoiser_inputs(L, B, seed + k)
+        z, eps = cases.loop_noise(T, B, L, seed + k)
+        jobs.append(den.make_job(structures_of(den, prot), list(range(B))))
+        xs.append(z.reshape(-1, 3).to(DEV))
+        ns.append(eps.reshape(T, -1, 3).to(DEV))
+    one_by_one = [den.sample(j, x, n, tb) for j, x, n in zip(jobs, xs, ns)]
+    together = den.sample_many(jobs, xs, ns, tb)
+    torch.cuda.synchronize()
+    for a, b in zip(one_by_one, together):
+        assert torch.equal(a, b)
+
+
 def test_split_f16_agrees_with_f32_mfma_and_survives_large_latents(sd):
     """The contraction modes agree to fp32 rounding level, also when the latent is far outside
     the trained range (|x| ~ 3000, as late steps of an untrained sampler produce): the only
