@@ -164,13 +164,13 @@ def standard_bonds(top):
 
 def high_order_edges(edges, order, n_atoms):
     """get_high_order_edge (protein_module.py:536-564): pairs (i < j) within `order` bonds, row-major."""
-    adj = torch.zeros(n_atoms, n_atoms, dtype=torch.int64)
+    adj = torch.zeros(n_atoms, n_atoms)                      # float: the reachability products go through BLAS
     adj[edges[:, 0], edges[:, 1]] = 1
     adj[edges[:, 1], edges[:, 0]] = 1
-    eye = torch.eye(n_atoms, dtype=torch.int64)
-    mats = [eye, ((adj + eye) > 0).long()]
+    eye = torch.eye(n_atoms)
+    mats = [eye, ((adj + eye) > 0).float()]
     for i in range(2, order + 1):
-        mats.append(((mats[i - 1] @ mats[1]) > 0).long())
+        mats.append(((mats[i - 1] @ mats[1]) > 0).float())
     om = torch.zeros_like(adj)
     for i in range(1, order + 1):
         om += (mats[i] - mats[i - 1]) * i
