@@ -40,7 +40,10 @@ void set_max_lds(const void *fn, size_t bytes);     // denoiser_kernels.hip
 
 namespace {
 
-constexpr int MF_WAVES = 8;
+constexpr int MF_WAVES = 8;                  // waves of the packing kernel and of the conv kernel at depth 1, 2
+// depths 0 and 1 fit 168 registers per lane (137 / 168 without the SLP vectoriser): three waves per SIMD, 12 per workgroup;
+// depth 2 needs 191: two per SIMD
+__host__ __device__ constexpr int conv_waves(int depth) { return depth == 2 ? 8 : 12; }
 
 // 2^(target - floor(log2 m)): the power of two that moves m (> 0) into [2^target, 2^(target + 1))
 DEV float pow2_scale(float m, int target) {
@@ -155,7 +158,7 @@ __host__ __device__ constexpr int tiles_of(int depth) { return depth == 0 ? 8 : 
 __host__ __device__ constexpr int image_bytes(int depth) { return (tiles_of(depth) + 2) * 3 * 128 * 16 + (4 + 12 * 12 + 12 * 16) * 4; }
 
 // Built by one workgroup of 64 MF_WAVES threads into `img` (LDS or global memory); `red`: 2 MF_WAVES floats of LDS.
-template <int DEPTH>
+template <int DEPTH, int NW>
 DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
     constexpr int NT = tiles_of(DEPTH);
     u32x4 *A3 = img, *A0 = img + NT * 3 * 128;
@@ -166,10 +169,10 @@ DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
     {
         constexpr int N3 = DEPTH == 0 ? 192 : (DEPTH == 1 ? 288 : 384);
         float m3 = 0.f, m0 = 0.f;
-        for (int i = threadIdx.x; i < N3 * 36; i += 64 * MF_WAVES) m3 = fmaxf(m3, fabsf(a.fc3_w[i]));
-        for (int i = threadIdx.x; i < N3; i += 64 * MF_WAVES) m3 = fmaxf(m3, fabsf(a.fc3_b[i]));
-        for (int i = threadIdx.x; i < 36 * 36; i += 64 * MF_WAVES) m0 = fmaxf(m0, fabsf(a.fc0_w[i]));
-        for (int i = threadIdx.x; i < 36; i += 64 * MF_WAVES) m0 = fmaxf(m0, fabsf(a.fc0_b[i]));
+        for (int i = threadIdx.x; i < N3 * 36; i += 64 * NW) m3 = fmaxf(m3, fabsf(a.fc3_w[i]));
+        for (int i = threadIdx.x; i < N3; i += 64 * NW) m3 = fmaxf(m3, fabsf(a.fc3_b[i]));
+        for (int i = threadIdx.x; i < 36 * 36; i += 64 * NW) m0 = fmaxf(m0, fabsf(a.fc0_w[i]));
+        for (int i = threadIdx.x; i < 36; i += 64 * NW) m0 = fmaxf(m0, fabsf(a.fc0_b[i]));
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             m3 = fmaxf(m3, __shfl_xor(m3, m, 64));
@@ -177,7 +180,7 @@ DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
         }
         if (lane == 0) { red[2 * wave] = m3; red[2 * wave + 1] = m0; }
         __syncthreads();
-        for (int w = 0; w < MF_WAVES; ++w) { m3 = fmaxf(m3, red[2 * w]); m0 = fmaxf(m0, red[2 * w + 1]); }
+        for (int w = 0; w < NW; ++w) { m3 = fmaxf(m3, red[2 * w]); m0 = fmaxf(m0, red[2 * w + 1]); }
         S_W3 = pow2_scale(m3, 8);
         S_W0 = pow2_scale(m0, 8);
     }
@@ -185,7 +188,7 @@ DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
     {
         // emb0 rows: [w(type recv), w(type snd), w(smearing 0..7), bias, 0]  (12 floats), emb3 rows: [w 0..11, bias, 0 0 0] (16)
         float *e0 = scales + 4, *e3 = e0 + 12 * 12;
-        for (int i = threadIdx.x; i < 12 * 12; i += 64 * MF_WAVES) {
+        for (int i = threadIdx.x; i < 12 * 12; i += 64 * NW) {
             const int o = i / 12, k = i % 12;
             float v = 0.f;
             if (k < 2) v = a.emb_in == 14 ? a.emb0_w[o * 14 + k] : 0.f;
@@ -193,13 +196,13 @@ DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
             else if (k == 10) v = a.emb0_b[o];
             e0[i] = v;
         }
-        for (int i = threadIdx.x; i < 12 * 16; i += 64 * MF_WAVES) {
+        for (int i = threadIdx.x; i < 12 * 16; i += 64 * NW) {
             const int o = i / 16, k = i % 16;
             e3[i] = k < 12 ? a.emb3_w[o * NS + k] : (k == 12 ? a.emb3_b[o] : 0.f);
         }
     }
     // fragment (block, k-step) of lane l = row (l & 31), k-slots 8 (l >> 5) + 0..7
-    for (int f = threadIdx.x; f < (NT + 2) * 3 * 64; f += 64 * MF_WAVES) {
+    for (int f = threadIdx.x; f < (NT + 2) * 3 * 64; f += 64 * NW) {
         const int l = f & 63, blk = (f >> 6) / 3, ks = (f >> 6) % 3;
         const int row = l & 31, hb = l >> 5;
         float v[8];
@@ -230,14 +233,15 @@ DEV void build_image(const codlad_tp_conv_args &a, u32x4 *img, float *red) {
 template <int DEPTH>
 __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_pack_kernel(codlad_tp_conv_args a, u32x4 *img) {
     __shared__ float red[2 * MF_WAVES];
-    build_image<DEPTH>(a, img, red);
+    build_image<DEPTH, MF_WAVES>(a, img, red);
 }
 
 template <int DEPTH>
-__global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_conv_args a) {
+__global__ __launch_bounds__(64 * conv_waves(DEPTH)) void tp_conv_mfma_kernel(codlad_tp_conv_args a) {
+    constexpr int NW = conv_waves(DEPTH);
     constexpr int NT = tiles_of(DEPTH);
     constexpr int D_OUT = width_of(DEPTH + 1);
-    // the read-only image (build_image), then the waves' output rows (48 floats each) and 2 MF_WAVES floats for build_image
+    // the read-only image (build_image), then the waves' output rows (48 floats each) and 2 NW floats for build_image
     extern __shared__ __align__(16) u32x4 lds[];
     const u32x4 *A3 = lds, *A0 = lds + NT * 3 * 128;
     float *out_sh = reinterpret_cast<float *>(lds + image_bytes(DEPTH) / 16);
@@ -247,20 +251,20 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
     // ---- the read-only image: packed here by every workgroup, or copied when the caller packed it once (a.packed)
     if (a.packed) {
         const u32x4 *src = static_cast<const u32x4 *>(a.packed);
-        constexpr int N16 = image_bytes(DEPTH) / 16, PER = (N16 + 64 * MF_WAVES - 1) / (64 * MF_WAVES);
+        constexpr int N16 = image_bytes(DEPTH) / 16, PER = (N16 + 64 * NW - 1) / (64 * NW);
         u32x4 v[PER];                                       // all of a thread's loads in flight, then the stores
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * 64 * MF_WAVES;
+            const int i = threadIdx.x + k * 64 * NW;
             if (i < N16) v[k] = src[i];
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * 64 * MF_WAVES;
+            const int i = threadIdx.x + k * 64 * NW;
             if (i < N16) lds[i] = v[k];
         }
     } else {
-        build_image<DEPTH>(a, lds, out_sh + MF_WAVES * 48);
+        build_image<DEPTH, NW>(a, lds, out_sh + NW * 48);
     }
     __syncthreads();
     const float *scales = reinterpret_cast<const float *>(lds + (NT + 2) * 3 * 128);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
     constexpr float C1E = DEPTH == 1 ? 0.86602540378443865f : 0.5f;
     constexpr float C0O = 0.5f;
 
-    for (int n = blockIdx.x * MF_WAVES + wave; n < a.n_recv; n += gridDim.x * MF_WAVES) {      // wave-uniform
+    for (int n = blockIdx.x * NW + wave; n < a.n_recv; n += gridDim.x * NW) {      // wave-uniform
         const int e0 = __builtin_amdgcn_readfirstlane(a.ptr[n]), e1 = __builtin_amdgcn_readfirstlane(a.ptr[n + 1]);
         const float xr = a.xyz_recv[3 * n], yr = a.xyz_recv[3 * n + 1], zr = a.xyz_recv[3 * n + 2];
         float hr[NS];
@@ -590,15 +594,16 @@ __global__ __launch_bounds__(64 * MF_WAVES) void tp_conv_mfma_kernel(codlad_tp_c
 
 template <int DEPTH>
 void launch(const codlad_tp_conv_args &a, hipStream_t st) {
-    const size_t lds = (size_t)image_bytes(DEPTH) + (MF_WAVES * 48 + 2 * MF_WAVES) * sizeof(float);
+    constexpr int NW = conv_waves(DEPTH);
+    const size_t lds = (size_t)image_bytes(DEPTH) + (NW * 48 + 2 * NW) * sizeof(float);
     static bool raised = false;
     if (!raised) {
         set_max_lds(reinterpret_cast<const void *>(tp_conv_mfma_kernel<DEPTH>), lds);
         raised = true;
     }
-    const int wanted = (a.n_recv + MF_WAVES - 1) / MF_WAVES;
+    const int wanted = (a.n_recv + NW - 1) / NW;
     const int grid = wanted < num_cu() ? wanted : num_cu();
-    hipLaunchKernelGGL((tp_conv_mfma_kernel<DEPTH>), dim3(grid), dim3(64 * MF_WAVES), lds, st, a);
+    hipLaunchKernelGGL((tp_conv_mfma_kernel<DEPTH>), dim3(grid), dim3(64 * NW), lds, st, a);
 }
 
 }  // namespace
