@@ -20,7 +20,7 @@
 //   * per node the 48 output channels are accumulated per lane over the steps and summed over the 32 lanes of a half
 //     by shuffles at the end: a fixed order per node, whatever shares the launch.
 // The packed weights (13 blocks x 3 k-steps x (hi, lo) x 1 KB + fc.0's 12 KB = 90 KB for depth 2) live in LDS for the
-// workgroup's lifetime; workgroups are persistent (one per CU, 8 waves).
+// workgroup's lifetime; workgroups are persistent (one per CU, 12 waves).
 //
 // Powers of two keep the fp16 halves in range whatever the magnitudes are: every operand is scaled before the split so
 // that its largest element lands in a fixed binade - the two weight matrices once per workgroup (largest |w| -> [256, 512)),
@@ -41,9 +41,9 @@ void set_max_lds(const void *fn, size_t bytes);     // denoiser_kernels.hip
 namespace {
 
 constexpr int MF_WAVES = 8;                  // waves of the packing kernel and of the conv kernel at depth 1, 2
-// depths 0 and 1 fit 168 registers per lane (137 / 168 without the SLP vectoriser): three waves per SIMD, 12 per workgroup;
-// depth 2 needs 191: two per SIMD
-__host__ __device__ constexpr int conv_waves(int depth) { return depth == 2 ? 8 : 12; }
+// 12 waves per workgroup = three per SIMD: without the SLP vectoriser the kernel needs 137 / 152 / 191 registers per lane at
+// depth 0 / 1 / 2, and held to the 168 of three waves depth 2 spills three of them (303 -> 272 us on a 1.1 M-edge graph)
+__host__ __device__ constexpr int conv_waves(int) { return 12; }
 
 // 2^(target - floor(log2 m)): the power of two that moves m (> 0) into [2^target, 2^(target + 1))
 DEV float pow2_scale(float m, int target) {
