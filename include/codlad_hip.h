@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 10
+#define CODLAD_ABI_VERSION 11
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
