@@ -1,7 +1,7 @@
 """Latency of small jobs (the regime of one GPU's shard of cfg 3, and of cfg 1): the 100-step DDPM loop on
 1 protein of 87 residues, 1 of 300, an 8-protein shard of cfg 3 (~1.3 k nodes) and all 64 proteins of cfg 3.
 
-    python tools/small_job_latency.py [--only N] [--reps R] [--graph 0|1]
+    python tools/small_job_latency.py [--only N] [--reps R]
 """
 import argparse
 import sys
@@ -17,7 +17,6 @@ from codlad_amd.engine import Denoiser                                          
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--graph", type=int, default=-1, help="-1: library default; 0 / 1: force HIP-graph replay off / on")
 args = ap.parse_args()
 
 torch.set_grad_enabled(False)
@@ -28,7 +27,6 @@ shard = parallel.shard_units([parallel.unit_cost(L) for L in cfg3], 8)[0]
 CASES = [("1 protein, L=87", [87]), ("1 protein, L=300", [300]),
          ("cfg3 shard of one GPU (1/8, LPT): %d proteins" % len(shard), [cfg3[u] for u in shard]),
          ("cfg3, all 64 proteins", cfg3)]
-kw = {} if args.graph < 0 else {"graph": bool(args.graph)}
 for k, (label, lens) in enumerate(CASES):
     if args.only >= 0 and k != args.only:
         continue
@@ -39,11 +37,11 @@ for k, (label, lens) in enumerate(CASES):
     job = den.make_job(st, list(range(len(lens))))
     xT = torch.randn(job.n_nodes, 3, device="cuda")
     eps = torch.randn(100, job.n_nodes, 3, device="cuda")
-    den.sample(job, xT, eps, tb, **kw)
+    den.sample(job, xT, eps, tb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        den.sample(job, xT, eps, tb, **kw)
+        den.sample(job, xT, eps, tb)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
     print(f"{label:48s} {job.n_nodes:6d} nodes: {dt * 1e3:8.2f} ms per 100-step loop = {dt / 100 * 1e6:7.1f} us/step, "
