@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
-SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_tile_kernels.hip",
+SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_upd1_kernel.hip", "edge_tile_kernels.hip",
            "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
            "ic_decoder_kernels.hip", "encoder_kernels.hip", "encoder_mfma_kernel.hip", "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
@@ -28,6 +28,10 @@ EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip":
                "edge_tile_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_msg_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_upd_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               # one wave per SIMD: with a 512-register budget hipcc selects the AGPR form of every MFMA (accumulators in
+               # AGPRs, ~450 v_accvgpr_read/write per tile around the vector work on them); the VGPR form keeps the
+               # accumulators where GELU / LayerNorm read them, and the register-resident weights are placed in AGPRs by hand
+               "edge_upd1_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "node_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "encoder_common.h"), os.path.join(CSRC, "edge_args.h"), os.path.join(CSRC, "node_args.h"),
            os.path.join(HERE, "..", "include", "codlad_hip.h")]

@@ -114,7 +114,11 @@ DEV void tile_load_edge(Tile &t, const float *block, int e, int h) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(p + (8 * bo + 2 * q + h) * 32);
+#ifdef CODLAD_NO_STREAM_HINT     // A/B builds: default cache policy everywhere (does the edge state of a small job stay in the Infinity Cache?)
+            const f32x4 v = *src;
+#else
             const f32x4 v = STREAM ? __builtin_nontemporal_load(src) : *src;
+#endif
             t.b[bo][4 * q + 0] = v.x;
             t.b[bo][4 * q + 1] = v.y;
             t.b[bo][4 * q + 2] = v.z;
@@ -145,8 +149,12 @@ DEV void tile_store_edge(const Tile &t, float *block, int e, int h) {
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = {t.b[bo][4 * q + 0], t.b[bo][4 * q + 1], t.b[bo][4 * q + 2], t.b[bo][4 * q + 3]};
             f32x4 *dst = reinterpret_cast<f32x4 *>(p + (8 * bo + 2 * q + h) * 32);
+#ifdef CODLAD_NO_STREAM_HINT
+            *dst = v;
+#else
             if (STREAM) __builtin_nontemporal_store(v, dst);
             else *dst = v;
+#endif
         }
 }
 
@@ -364,14 +372,16 @@ DEV void tile_unsplit_scale_add_row(Tile &t, float scale, const float *row, int 
 }
 
 // PRESPLIT: `in` holds the stored (pre-split) form of an edge tile; its fragments are taken as they are.
-template <int TERMS, int KS0, int NKS, bool GELU_IN, bool TRANSPOSED = false, bool PRESPLIT = false>
+// AHEAD = groups the fragment reads run ahead of their use (ring of AHEAD + 1 pairs): 2 for the kernels with two waves per
+// SIMD; the one-wave-per-SIMD edge update takes 1 (8 registers fewer; a group is then ~130 cycles against ~64 of LDS latency).
+template <int TERMS, int KS0, int NKS, bool GELU_IN, bool TRANSPOSED = false, bool PRESPLIT = false, int AHEAD = 2>
 DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk) {
     static_assert(!(GELU_IN && PRESPLIT), "a stored tile is never an activation input");
     const u32x4 *w = wl + lane;
-    constexpr int G0 = KS0 * 4, NG = NKS * 4;
-    u32x4 ring[3][2];
+    constexpr int G0 = KS0 * 4, NG = NKS * 4, R = AHEAD + 1;
+    u32x4 ring[R][2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AHEAD; ++g) {
         ring[g][0] = w[((G0 + g) * 2 + 0) * 64];
         ring[g][1] = w[((G0 + g) * 2 + 1) * 64];
     }
@@ -384,12 +394,12 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int ks = KS0 + (g >> 2), bo = g & 3;
-        if (g + 2 < NG) {
-            ring[(g + 2) % 3][0] = w[((G0 + g + 2) * 2 + 0) * 64];
-            ring[(g + 2) % 3][1] = w[((G0 + g + 2) * 2 + 1) * 64];
+        if (g + AHEAD < NG) {
+            ring[(g + AHEAD) % R][0] = w[((G0 + g + AHEAD) * 2 + 0) * 64];
+            ring[(g + AHEAD) % R][1] = w[((G0 + g + AHEAD) * 2 + 1) * 64];
         }
         if (!PRESPLIT && ks + 1 < KS0 + NKS) split_pair<GELU_IN>(xn, in, ks + 1, bo, gk);
-        mfma_f16<TERMS, TRANSPOSED>(acc.b[bo], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), x);
+        mfma_f16<TERMS, TRANSPOSED>(acc.b[bo], as_f16x8(ring[g % R][0]), as_f16x8(ring[g % R][1]), x);
         __builtin_amdgcn_sched_barrier(0);
         if (bo == 3) {
             if (PRESPLIT) { if (ks + 1 < KS0 + NKS) presplit_frag(x, in, ks + 1); }
@@ -399,9 +409,9 @@ DEV void gemm_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const 
 }
 
 // acc += W @ act(in): GELU_IN applies GELU to `in` on the fly (see split_pair)
-template <int TERMS, bool GELU_IN, bool TRANSPOSED = false, bool PRESPLIT = false>
+template <int TERMS, bool GELU_IN, bool TRANSPOSED = false, bool PRESPLIT = false, int AHEAD = 2>
 DEV void gemm128_h_lds(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk) {
-    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED, PRESPLIT>(acc, in, wl, lane, gk);
+    gemm_h_lds<TERMS, 0, 8, GELU_IN, TRANSPOSED, PRESPLIT, AHEAD>(acc, in, wl, lane, gk);
 }
 
 // The same k-step with the weight fragments fetched from global memory (L2-resident) through a

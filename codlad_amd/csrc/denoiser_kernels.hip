@@ -493,12 +493,19 @@ hipError_t codlad_take_attr_error() {
 void launch_edge_tile(int terms, bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st);
 void launch_edge_msg(int terms, const EdgeArgs &ea, hipStream_t st);
 void launch_edge_upd(int terms, const EdgeArgs &ea, hipStream_t st);
+void launch_edge_upd1(int terms, const EdgeArgs &ea, hipStream_t st);     // edge_upd1_kernel.hip: one wave per SIMD
+int edge_upd_variant();
 
 template <int TERMS>
 static void launch_edge_h(bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st) {
     if (tile_list) return launch_edge_tile(TERMS, update, ea, tile_list, n_tiles, st);
-    if (update) launch_edge_upd(TERMS, ea, st);
-    else launch_edge_msg(TERMS, ea, st);
+    if (update) {
+        // upd1_kernel_h gives every node two tiles: worth it while (nearly) every node has two (n_tiles counts the
+        // non-empty ones; 0 = the caller gave no tile list, i.e. nothing is known about the job)
+        const bool two_tiles_each = n_tiles > 0 && 20ll * n_tiles >= 19ll * 2 * ea.n_nodes;
+        if ((edge_upd_variant() == 1 && two_tiles_each) || edge_upd_variant() == 2) launch_edge_upd1(TERMS, ea, st);   // 2: always (tests)
+        else launch_edge_upd(TERMS, ea, st);
+    } else launch_edge_msg(TERMS, ea, st);
 }
 
 static void launch_edge_now(bool update, const EdgeArgs &ea, int precision, hipStream_t st, const int2 *tile_list,
@@ -601,6 +608,7 @@ static int edge_tile_max_nodes() { return option_or(CODLAD_OPT_EDGE_TILE_MAX_NOD
 static int nodeq_max_tiles() { return option_or(CODLAD_OPT_NODEQ_MAX_TILES, "CODLAD_NODEQ_MAX_TILES", 256); }
 int dec_edge_variant() { return option_or(CODLAD_OPT_DEC_EDGE_VARIANT, "CODLAD_DEC_EDGE_VARIANT", 0); }
 int tp_conv_variant() { return option_or(CODLAD_OPT_TP_CONV_VARIANT, "CODLAD_TP_CONV_VARIANT", 0); }
+int edge_upd_variant() { return option_or(CODLAD_OPT_EDGE_UPD_VARIANT, "CODLAD_EDGE_UPD_VARIANT", 0); }
 
 // node_wide_kernels.hip
 void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st);
@@ -931,12 +939,13 @@ extern "C" int codlad_bench_edge_launch(const codlad_denoiser_weights *w, const 
         set_msg_scales(ea, split, L.b2, Lh.b2, Lh.e1, Lh.e2);
     } else {
         ea.hE_out = ws->hE; ea.P = ws->PQ + 2 * NS; ea.Q = ws->PQ + 3 * NS;
+        ea.S = ws->S;      // unused by the edge update; the diagnostic -DU1_STAMP build of upd1_kernel_h reports through it
         ea.W1 = L.W11e; ea.W2 = L.W12; ea.W3 = L.W13;
         ea.mods3 = mods_t + 6 * HD;
         ea.W1h = Lh.W11e; ea.W2h = Lh.W12; ea.W3h = Lh.W13;
         set_upd_scales(ea, split, L, Lh);
     }
-    launch_edge(which == 1, ea, w->precision, (hipStream_t)stream);
+    launch_edge(which == 1, ea, w->precision, (hipStream_t)stream, nullptr, ws->n_tiles);
     return codlad_check_launch("codlad_bench_edge_launch");
 }
 

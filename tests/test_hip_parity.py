@@ -17,6 +17,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+EDGE_UPD_DEFAULT = 0      # the library's default CODLAD_OPT_EDGE_UPD_VARIANT
 
 
 def rel_err(a, b):
@@ -634,3 +635,34 @@ def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
         a, b = int(off[k]), int(off[k + 1])
         ref = oden.forward(sd, x[a:b].cpu()[None], torch.tensor([600]), cg_xyz, cg_z, m)
         assert rel_err(outs[1][0][a:b], ref[0]) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x4"])
+def test_edge_update_one_wave_per_simd_is_bit_identical(sd, precision):
+    """upd1_kernel_h (round 4: one wave per SIMD, five k-steps of W11e resident in registers, the next tile's rows and
+    Q rows prefetched) runs the arithmetic of upd_kernel_h in the same order: bit-identical, with and without the
+    hoisted layer-0 terms, on lengths that give empty, partial and full second halves and one-tile nodes in a row."""
+    lens = [5, 31, 32, 33, 47, 64, 87, 120]
+    prots = [synth.make_protein(L, 400 + i, n_frames=1) for i, L in enumerate(lens)]
+    xyz = [torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in prots]
+    zz = [torch.from_numpy(p["z_full"])[1:-1] for p in prots]
+    members = list(range(len(lens))) + [7, 6, 0]
+    n = sum(lens[m] for m in members)
+    x = synth.gaussian((n, 3), 27).to(DEV)
+    T = 3
+    eps = synth.gaussian((T, n, 3), 28).to(DEV)
+    outs = []
+    _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, 0)      # the per-node kernels, whatever the job size
+    try:
+        for variant in (0, 2):         # 2: upd1_kernel_h whatever the job (1 leaves jobs with many one-tile nodes to upd_kernel_h)
+            _lib.set_option(_lib.OPT_EDGE_UPD_VARIANT, variant)
+            d = Denoiser(sd, DEV, precision=precision)
+            for hoist in (True, False):
+                job = d.make_job(d.prepare_structures(xyz, zz, hoist_layer0=hoist), members)
+                outs.append((d.forward(job, x, 600), d.sample(job, x, eps, tables(T))))
+    finally:
+        _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, 1 << 30)
+        _lib.set_option(_lib.OPT_EDGE_UPD_VARIANT, EDGE_UPD_DEFAULT)
+    for k in range(2):
+        assert bool(torch.isfinite(outs[k][0]).all())
+        assert torch.equal(outs[k][0], outs[2 + k][0]) and torch.equal(outs[k][1], outs[2 + k][1]), (precision, k)

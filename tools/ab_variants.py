@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from codlad_amd import _lib  # noqa: E402
 
-OPTS = {"NODEQ_MAX_TILES": 0, "EDGE_TILE_MAX_NODES": 1, "DEC_EDGE_VARIANT": 3, "TP_CONV_VARIANT": 4}
+OPTS = {"NODEQ_MAX_TILES": 0, "EDGE_TILE_MAX_NODES": 1, "DEC_EDGE_VARIANT": 3, "TP_CONV_VARIANT": 4, "EDGE_UPD_VARIANT": 5, "EDGE_MSG_VARIANT": 6}
 
 
 def main():
