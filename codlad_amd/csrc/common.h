@@ -707,14 +707,27 @@ DEV void tile_modulate(Tile &t, const float *shift, const float *scale, const fl
         }
 }
 
-// One reverse-diffusion update of a scalar (gaussian_diffusion.py:313-318, 364-367, 246-249, 446),
+// One reverse-diffusion update of a scalar (gaussian_diffusion.py:303-349, 364-367, 246-249, 446),
 // every product and sum rounded separately like the reference's elementwise tensor ops.
+// cf = one row of Tables.step_coefficients(): {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1,
+// posterior_mean_coef2, log variance (minimum, or THE log variance of the fixed-variance samplers), log beta, nonzero mask,
+// mode}; mode bits (p_mean_variance's branches): 1 = the model predicts x_0 (ModelMeanType.START_X) instead of the noise,
+// 2 = fixed variance (FIXED_SMALL / FIXED_LARGE: cf[4] is the step's log variance, `v` is not read), 4 = clip_denoised
+// (pred_xstart clamped into [-1, 1]).  mode 0 = epsilon prediction with the learned-range variance, what test.py samples with.
 // *x0_out (optional) receives pred_xstart, the self-conditioning input of the next step.
-DEV float ddpm_step(float xt, float eps, float v, const float *cf, float noise, float *x0_out = nullptr) {
+#define CODLAD_DDPM_START_X 1
+#define CODLAD_DDPM_FIXED_VAR 2
+#define CODLAD_DDPM_CLIP 4
+DEV float ddpm_step(float xt, float out, float v, const float *cf, float noise, float *x0_out = nullptr) {
 #pragma clang fp contract(off)
-    const float frac = (v + 1.0f) / 2.0f;
-    const float logvar = frac * cf[5] + (1.0f - frac) * cf[4];
-    const float x0 = cf[0] * xt - cf[1] * eps;
+    const int mode = (int)cf[7];
+    float logvar = cf[4];
+    if (!(mode & CODLAD_DDPM_FIXED_VAR)) {
+        const float frac = (v + 1.0f) / 2.0f;
+        logvar = frac * cf[5] + (1.0f - frac) * cf[4];
+    }
+    float x0 = (mode & CODLAD_DDPM_START_X) ? out : cf[0] * xt - cf[1] * out;
+    if (mode & CODLAD_DDPM_CLIP) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
     const float mean = cf[2] * x0 + cf[3] * xt;
     if (x0_out) *x0_out = x0;
     return mean + (cf[6] * expf(0.5f * logvar)) * noise;

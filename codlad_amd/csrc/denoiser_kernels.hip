@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void final_kernel(FinalArgs a) {
     }
     if (l < 3) {                                        // lane k updates component k
         const float eps = l == 0 ? o[0] : (l == 1 ? o[1] : o[2]);
-        const float vv = l == 0 ? o[3] : (l == 1 ? o[4] : o[5]);
+        const float vv = l == 0 ? o[3] : (l == 1 ? o[4] : o[5]);      // (zeros for a 3-row head: fixed-variance samplers)
         const size_t i = (size_t)n * 3 + l;
         a.x[i] = ddpm_step(a.x[i], eps, vv, a.coef, a.noise[i], a.x_start ? a.x_start + i : nullptr);
     }
@@ -405,7 +405,10 @@ __global__ void ddpm_kernel(const float *x, const float *out, const float *noise
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes * 3) return;
     const int n = i / 3, k = i - 3 * n;
-    x_out[i] = ddpm_step(x[i], out[n * 6 + k], out[n * 6 + 3 + k], cf.c, noise[i], x_start ? x_start + i : nullptr);
+    // a fixed-variance sampler's model has no variance channels (gaussian_diffusion.py:321-334: model_output stays [.., C])
+    const bool fixed = ((int)cf.c[7] & CODLAD_DDPM_FIXED_VAR) != 0;
+    const float o = fixed ? out[n * 3 + k] : out[n * 6 + k], v = fixed ? 0.f : out[n * 6 + 3 + k];
+    x_out[i] = ddpm_step(x[i], o, v, cf.c, noise[i], x_start ? x_start + i : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -828,7 +831,8 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
     CODLAD_REQUIRE(check_ws(ws), "incomplete workspace");
     CODLAD_REQUIRE(n_nodes > 0 && T > 0, "n_nodes and T must be positive");
     CODLAD_REQUIRE(!w->self_condition || x_start, "a self-conditioned model needs the x_start buffer");
-    CODLAD_REQUIRE(w->out_dim == 6, "the DDPM loop needs a diffusion model (eps | variance logits, out_dim 6)");
+    CODLAD_REQUIRE(w->out_dim == 6 || w->out_dim == 3,
+                   "the DDPM loop needs a model with 6 outputs (mean | variance logits) or 3 (fixed-variance samplers)");
     hipStream_t st = (hipStream_t)stream;
     // self-conditioning (gaussian_diffusion.py:530-547): step k reads the pred_xstart step k-1 wrote;
     // the first step gets none, which the model treats as zeros (latent_model.py:211)
@@ -841,7 +845,7 @@ extern "C" int codlad_sample_loop(const codlad_denoiser_weights *w, const int32_
         FinalArgs fa = {};
         fa.hV = ws->hV; fa.mods = mods_t + mods_offset(6); fa.out_w = w->out_w; fa.out_b = w->out_b;
         fa.n_nodes = n_nodes; fa.x = x; fa.noise = noise + (size_t)k * n_nodes * 3;
-        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start; fa.status = ws->status; fa.n_out = 6;
+        fa.coef = coef + (size_t)i * 8; fa.x_start = x_start; fa.status = ws->status; fa.n_out = w->out_dim;
         hipLaunchKernelGGL(final_kernel, dim3((n_nodes + 7) / 8), dim3(256), 0, st, fa);
     }
     return codlad_check_launch("codlad_sample_loop");

@@ -28,21 +28,34 @@ class ModelVarType(enum.Enum):
 
 
 class SpacedDiffusion(Tables):
-    """Respaced ancestral sampler (reference respace.py:65-114 + gaussian_diffusion.py:404-547),
-    epsilon-prediction mean with learned-range variance, which is what `create_diffusion`'s
-    defaults and test.py select."""
+    """Respaced ancestral sampler (reference respace.py:65-114 + gaussian_diffusion.py:404-547) with every branch of
+    p_mean_variance that `create_diffusion` can select (gaussian_diffusion.py:303-349): the model predicts the noise
+    (EPSILON, the default) or x_0 (START_X, test.py --predict_xstart); the variance is the learned range
+    (LEARNED_RANGE; LEARNED takes the same formula in the reference) or fixed (FIXED_SMALL / FIXED_LARGE, with a
+    model whose head has no variance channels); pred_xstart is optionally clipped into [-1, 1] (clip_denoised)."""
 
     def __init__(self, use_timesteps, betas, model_mean_type=ModelMeanType.EPSILON,
                  model_var_type=ModelVarType.LEARNED_RANGE, loss_type=None, self_condition=False):
-        if model_mean_type is not ModelMeanType.EPSILON or model_var_type is not ModelVarType.LEARNED_RANGE:
-            raise NotImplementedError("only epsilon prediction with LEARNED_RANGE variance is built "
-                                      "(the configuration test.py samples with)")
+        if model_mean_type is ModelMeanType.PREVIOUS_X:
+            raise NotImplementedError("ModelMeanType.PREVIOUS_X: create_diffusion never selects it and the reference's "
+                                      "p_mean_variance has no branch for it either (gaussian_diffusion.py:343-349)")
         super().__init__(betas, set(use_timesteps))
         self.use_timesteps = set(use_timesteps)
         self.original_num_steps = len(betas)
         self.model_mean_type, self.model_var_type = model_mean_type, model_var_type
         # reference gaussian_diffusion.py:172, 530-547: each step is conditioned on the previous pred_xstart
         self.loss_type, self.self_condition = loss_type, bool(self_condition)
+
+    @property
+    def fixed_variance(self):
+        return self.model_var_type in (ModelVarType.FIXED_SMALL, ModelVarType.FIXED_LARGE)
+
+    def coefficients(self, clip_denoised):
+        """The [T, 8] step table of the kernels for this sampler's branches (schedule.Tables.step_coefficients)."""
+        var = {ModelVarType.FIXED_SMALL: "fixed_small", ModelVarType.FIXED_LARGE: "fixed_large"}.get(self.model_var_type,
+                                                                                                      "learned_range")
+        return self.step_coefficients(predict_xstart=self.model_mean_type is ModelMeanType.START_X, var_type=var,
+                                      clip_denoised=bool(clip_denoised))
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -53,9 +66,9 @@ class SpacedDiffusion(Tables):
 
     @staticmethod
     def _check_args(clip_denoised, denoised_fn, cond_fn):
-        if clip_denoised or denoised_fn is not None or cond_fn is not None:
-            raise NotImplementedError("clip_denoised / denoised_fn / cond_fn are not used by the "
-                                      "reference's sampling call (test.py:533) and are not built")
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn (arbitrary Python callables inside the step) are not used by "
+                                      "the reference's sampling call (test.py:533) and are not built")
 
     def _draw_noise(self, x, generator=None):
         """T draws of randn_like(x), in loop order, consuming the device RNG stream exactly as the
@@ -94,7 +107,8 @@ class SpacedDiffusion(Tables):
             raise NotImplementedError("fused loop on a padded mixed-length batch; pass equal-length "
                                       "structures per call (what the reference's loaders produce)")
         T = self.num_timesteps
-        x0 = mod.engine().sample(job, img.reshape(-1, img.shape[-1]), eps.reshape(T, -1, img.shape[-1]), self)
+        x0 = mod.engine().sample(job, img.reshape(-1, img.shape[-1]), eps.reshape(T, -1, img.shape[-1]), self,
+                                 coef=self.coefficients(clip_denoised))
         return x0.view(img.shape)
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
@@ -129,10 +143,12 @@ class SpacedDiffusion(Tables):
         if noise is None:
             noise = torch.randn_like(x)
         C = x.shape[-1]
-        assert model_out.shape[-1] == 2 * C == 6, "latent_size 3 only"
+        assert C == 3 and model_out.shape[-1] == (C if self.fixed_variance else 2 * C), \
+            "latent_size 3 only; a fixed-variance sampler takes a model without variance channels " \
+            "(gaussian_diffusion.py:321-334)"
         import ctypes
         import numpy as np
-        coef = np.ascontiguousarray(self.step_coefficients()[i])
+        coef = np.ascontiguousarray(self.coefficients(clip_denoised)[i])
         xs = x.contiguous().float()
         out = torch.empty_like(xs)
         x_start = torch.empty_like(xs)
@@ -149,9 +165,11 @@ def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, 
                      self_condition=False):
     if timestep_respacing is None or timestep_respacing == "":
         timestep_respacing = [diffusion_steps]
-    if predict_xstart or not learn_sigma:
-        raise NotImplementedError("x0-prediction / fixed-sigma samplers are not on the built path")
+    # reference diffusion_and_flow/__init__.py:28-43
+    mean_type = ModelMeanType.START_X if predict_xstart else ModelMeanType.EPSILON
+    var_type = ModelVarType.LEARNED_RANGE if learn_sigma else (ModelVarType.FIXED_SMALL if sigma_small
+                                                               else ModelVarType.FIXED_LARGE)
     return SpacedDiffusion(use_timesteps=space_timesteps(diffusion_steps, timestep_respacing),
                            betas=named_betas(noise_schedule, diffusion_steps),
-                           model_mean_type=ModelMeanType.EPSILON, model_var_type=ModelVarType.LEARNED_RANGE,
+                           model_mean_type=mean_type, model_var_type=var_type,
                            loss_type=None, self_condition=self_condition)

@@ -73,9 +73,11 @@ class Tables:
         self.posterior_mean_coef1 = betas * np.sqrt(prev) / (1.0 - acp)
         self.posterior_mean_coef2 = (1.0 - prev) * np.sqrt(alphas) / (1.0 - acp)
 
-    def step_coefficients(self):
+    def step_coefficients(self, predict_xstart=False, var_type="learned_range", clip_denoised=False):
         """[T, 8] fp32 rows for codlad_sample_loop / codlad_ddpm_update: the float64 table entries
-        cast to fp32 exactly where the reference casts them (_extract_into_tensor: `.float()`)."""
+        cast to fp32 exactly where the reference casts them (_extract_into_tensor: `.float()`).
+        var_type "fixed_small" / "fixed_large" (gaussian_diffusion.py:321-334): column 4 holds the step's log
+        variance itself; column 7 is the mode word of include/codlad_hip.h (codlad_ddpm_update)."""
         T = self.num_timesteps
         c = np.zeros((T, 8), dtype=np.float32)
         c[:, 0] = self.sqrt_recip_alphas_cumprod.astype(np.float32)
@@ -85,4 +87,9 @@ class Tables:
         c[:, 4] = self.posterior_log_variance_clipped.astype(np.float32)
         c[:, 5] = np.log(self.betas).astype(np.float32)
         c[1:, 6] = 1.0  # no noise when t == 0
+        if var_type == "fixed_large":
+            c[:, 4] = np.log(np.append(self.posterior_variance[1], self.betas[1:])).astype(np.float32)
+        elif var_type not in ("fixed_small", "learned_range", "learned"):
+            raise ValueError(f"unknown variance type {var_type!r}")
+        c[:, 7] = (1 if predict_xstart else 0) + (2 if var_type.startswith("fixed") else 0) + (4 if clip_denoised else 0)
         return c

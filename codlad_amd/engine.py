@@ -246,7 +246,7 @@ class Denoiser:
             self.check_status(job)
         return out
 
-    def sample(self, job, x_T, noise, tables, check=True):
+    def sample(self, job, x_T, noise, tables, check=True, coef=None):
         """Full ancestral loop.  x_T [n_nodes,3]; noise [T,n_nodes,3] in loop order (first entry
         is used at step T-1); tables = diffusion_and_flow.schedule.Tables.  Returns x_0.
         check: after the loop, synchronise and raise if any step's output was not finite."""
@@ -254,13 +254,16 @@ class Denoiser:
         _require_cuda(noise, "noise")
         T = tables.num_timesteps
         assert noise.shape == (T, job.n_nodes, 3) and x_T.shape == (job.n_nodes, 3)
-        if self.weights.out_dim != 6:
-            raise ValueError("the DDPM loop needs a diffusion model; a flow-matching model is sampled with "
+        coef = tables.step_coefficients() if coef is None else coef
+        fixed_var = bool(int(coef[0, 7]) & 2)
+        if self.weights.out_dim != (3 if fixed_var else 6):
+            raise ValueError("the DDPM loop needs a model with 6 outputs (mean | variance logits), or 3 with a fixed-variance "
+                             "sampler (create_diffusion(learn_sigma=False)); a flow-matching model is sampled with "
                              "codlad_amd.diffusion_and_flow.ode.odeint")
         x = x_T.detach().clone().contiguous().float()
         noise = noise.contiguous().float()
         mods = self.step_mods(tables.timestep_map)
-        coef = torch.from_numpy(tables.step_coefficients()).to(self.device)
+        coef = torch.from_numpy(coef).to(self.device)
         st = job.structures
         self._fresh_features(st)
         x_start = torch.empty_like(x) if self.self_condition else None   # pred_xstart, step to step

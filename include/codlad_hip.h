@@ -222,7 +222,13 @@ int codlad_denoiser_forward(const codlad_denoiser_weights *w, const int32_t *nod
 
 /* Row 2: one reverse step given the model output (gaussian_diffusion.py:404-449, 262-360).
  * coef_host[8] = {sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2,
- *                 post_log_var_clipped, log_beta, nonzero(0/1), 0} for this step. */
+ *                 post_log_var_clipped, log_beta, nonzero(0/1), mode} for this step.
+ * mode selects p_mean_variance's branches (gaussian_diffusion.py:303-349), as a small integer kept in a float:
+ *   bit 1  the model predicts x_0 (ModelMeanType.START_X; test.py --predict_xstart) instead of the noise
+ *   bit 2  fixed variance (ModelVarType.FIXED_SMALL / FIXED_LARGE; create_diffusion(learn_sigma=False)): entry 4 holds the
+ *          step's log variance itself and model_out is [n_nodes][3] (no variance channels); otherwise [n_nodes][6]
+ *   bit 4  clip_denoised: pred_xstart clamped into [-1, 1]
+ * mode 0 = epsilon prediction, learned-range variance, no clipping: what test.py samples with. */
 int codlad_ddpm_update(const float *x, const float *model_out, const float *noise,
                        const float *coef_host, int n_nodes, float *x_out, float *x_start_out /* pred_xstart, may be NULL */,
                        void *stream);

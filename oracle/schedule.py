@@ -59,4 +59,6 @@ def make_schedule(timestep_respacing, diffusion_steps=1000):
         "posterior_mean_coef2": (1.0 - acp_prev) * np.sqrt(alphas) / (1.0 - acp),
         "posterior_log_variance_clipped": np.log(np.append(post_var[1], post_var[1:])),
         "log_betas": np.log(betas),
+        # ModelVarType.FIXED_LARGE (gaussian_diffusion.py:324-327)
+        "fixed_large_log_variance": np.log(np.append(post_var[1], betas[1:])),
     }

@@ -247,3 +247,23 @@ def validity_inputs(name):
 def npz_path(name):
     import os
     return os.path.join(os.path.dirname(__file__), "golden", name + ".npz")
+
+
+# Row 8f-1 (g15): the reference's e3nnPrior / e3nnEncoder forward over the e3nn_lite adapters (tools/gen_golden.py)
+#   name -> (residues, frames, weight seed, "seeded" | "trained_c2")      proteins: synth.make_protein(L, 40 + L, frames)
+E3NN_PRIOR_CASES = {"seeded_L46x2": (46, 2, 31, "seeded"), "c2_L87": (87, 1, 0, "trained_c2"), "c2_L5": (5, 1, 0, "trained_c2"),
+                    "seeded_L129": (129, 1, 33, "seeded")}
+#   name -> (residues, frames, weight seed)                                proteins: synth.make_protein(L, 50 + L, frames), atoms seed L
+E3NN_ENCODER_CASES = {"L46x2": (46, 2, 32), "L87": (87, 1, 34), "L12": (12, 1, 35)}
+
+
+# Row (a)2, the other branches of p_mean_variance (gaussian_diffusion.py:303-349), g16: name -> (n_cg, n_frames, seed, T,
+# create_diffusion kwargs, clip_denoised, flow-type model = a head without variance channels)
+SAMPLER_BRANCH_CASES = {
+    "xstart_L46_T10": (46, 2, 71, 10, dict(predict_xstart=True), False, False),
+    "xstart_clip_L46_T10": (46, 2, 72, 10, dict(predict_xstart=True), True, False),
+    "eps_clip_L87_T10": (87, 1, 73, 10, dict(), True, False),
+    "fixed_large_L46_T10": (46, 2, 74, 10, dict(learn_sigma=False), False, True),
+    "fixed_small_L87_T10": (87, 1, 75, 10, dict(learn_sigma=False, sigma_small=True), False, True),
+    "fixed_small_xstart_clip_L46_T10": (46, 1, 76, 10, dict(learn_sigma=False, sigma_small=True, predict_xstart=True), True, True),
+}

@@ -55,8 +55,6 @@ def test_unsupported_configurations_fail_loudly():
     sc = MPNN_models["mpnn_diffusion"](input_size=3, diffusion="diffusion", self_condition=True)
     assert sc.self_condition and tuple(sc.x_in.weight.shape) == (128, 6)        # latent_model.py:112-116
     with pytest.raises(NotImplementedError):
-        create_diffusion("100", predict_xstart=True)
-    with pytest.raises(NotImplementedError):
         build_vae("X9")                                                         # N6 / K3 / K4 / C2 exist
     from codlad_amd.models.vae_model import e3nnPrior
     with pytest.raises(NotImplementedError):
@@ -89,6 +87,20 @@ def test_create_diffusion_surface():
     gold = np.load(cases.npz_path("g1_schedule_100"))
     np.testing.assert_array_equal(d.betas, gold["betas"])
     assert create_diffusion("").num_timesteps == 1000
+    # every branch create_diffusion can select (reference diffusion_and_flow/__init__.py:28-43)
+    from codlad_amd.diffusion_and_flow import ModelMeanType, ModelVarType
+    assert (d.model_mean_type, d.model_var_type) == (ModelMeanType.EPSILON, ModelVarType.LEARNED_RANGE)
+    x0 = create_diffusion("10", predict_xstart=True)
+    assert x0.model_mean_type is ModelMeanType.START_X and x0.coefficients(False)[:, 7].tolist() == [1.0] * 10
+    big = create_diffusion("10", learn_sigma=False)
+    small = create_diffusion("10", learn_sigma=False, sigma_small=True)
+    assert big.model_var_type is ModelVarType.FIXED_LARGE and small.model_var_type is ModelVarType.FIXED_SMALL
+    assert big.coefficients(True)[:, 7].tolist() == [6.0] * 10 and small.coefficients(False)[:, 7].tolist() == [2.0] * 10
+    g10 = np.load(cases.npz_path("g1_schedule_10"))
+    np.testing.assert_array_equal(small.coefficients(False)[:, 4], g10["posterior_log_variance_clipped"].astype(np.float32))
+    # FIXED_LARGE: log(append(posterior_variance[1], betas[1:])) (gaussian_diffusion.py:324-327)
+    assert big.coefficients(False)[0, 4] == g10["posterior_log_variance_clipped"].astype(np.float32)[0]
+    np.testing.assert_array_equal(big.coefficients(False)[1:, 4], g10["log_betas"].astype(np.float32)[1:])
 
 
 def test_vae_checkpoint_layouts(tmp_path):
@@ -236,6 +248,37 @@ def test_p_sample_loop_like_test_py():
     b = diffusion.p_sample_loop(lambda x, t, **kw: model(x, t, **kw), cat_z.shape, cat_z, clip_denoised=False,
                                 model_kwargs=kwargs)
     assert torch.equal(a, b)
+
+
+@gpu
+@pytest.mark.parametrize("name", list(cases.SAMPLER_BRANCH_CASES))
+def test_sampler_branches_like_the_reference(name):
+    """create_diffusion(predict_xstart / learn_sigma / sigma_small).p_sample_loop(..., clip_denoised=...) against the
+    reference's own loops (g16): the fused device loop and the generic per-step path, which agree bit for bit."""
+    L, B, seed, T, kw, clip, three = cases.SAMPLER_BRANCH_CASES[name]
+    model = MPNN_models["mpnn_diffusion"](input_size=3, unconditional=True, diffusion="fm" if three else "diffusion",
+                                          self_condition=False)
+    model.load_state_dict(synth.denoiser_state_dict(cases.WEIGHT_SEED, flow=three), strict=True)
+    model = model.to(DEV).eval()
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    batch = to_dev(batch)
+    z, eps = cases.loop_noise(T, B, L, seed)
+    gold = np.load(cases.npz_path(f"g16_sampler_{name}"))
+    diffusion = create_diffusion(str(T), noise_schedule="linear", **kw)
+    kwargs = dict(y=None, mask=mask.to(DEV), batch=batch)
+    fused = diffusion.p_sample_loop(model.forward, z.shape, z.to(DEV), clip_denoised=clip, model_kwargs=kwargs, device=DEV,
+                                    step_noise=eps.to(DEV))
+    assert rel_err(fused, gold["sample"]) < 2e-5
+    traj = [o["sample"] for o in diffusion.p_sample_loop_progressive(lambda x, t, **k: model(x, t, **k), z.shape, z.to(DEV),
+                                                                     clip_denoised=clip, model_kwargs=kwargs, device=DEV,
+                                                                     step_noise=eps.to(DEV))]
+    assert torch.equal(traj[-1], fused)
+    for k in range(T):
+        assert rel_err(traj[k], gold["traj"][k]) < 2e-5, k
+    if not three:
+        with pytest.raises(AssertionError):                 # a 6-output model under a fixed-variance sampler: as in the reference
+            next(create_diffusion(str(T), learn_sigma=False).p_sample_loop_progressive(
+                lambda x, t, **k: model(x, t, **k), z.shape, z.to(DEV), model_kwargs=kwargs, device=DEV))
 
 
 @gpu
