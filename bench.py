@@ -143,10 +143,12 @@ class Workload:
         self.csr = self.dec.build_csr(self.cg_xyz, self.job.sample_lens, sample_range=self.sample_range,
                                       max_edges=self.max_dir_edges)
 
-    def run(self):
-        """CA traces + noise (HBM) -> all-atom coordinates (HBM) for this rank's structures."""
+    def run(self, streams=None):
+        """CA traces + noise (HBM) -> all-atom coordinates (HBM) for this rank's structures.  streams: None = as a user's call
+        runs (codlad_amd.engine.Denoiser.sample: a large job goes as two half-jobs on two HIP streams), 1 = everything on the
+        current stream (the probe pass, where a launch's duration has to be the kernel's own)."""
         self.prepass()
-        x0 = self.latent if self.decode_only else self.den.sample(self.job, self.x_T, self.noise, self.tables)
+        x0 = self.latent if self.decode_only else self.den.sample(self.job, self.x_T, self.noise, self.tables, streams=streams)
         return self.decode(x0)
 
     def decode(self, x0, normalised=True):
@@ -245,7 +247,7 @@ def probe_edge_kernels(wl):
     lib = _lib.lib()
     lib.codlad_probe_edge_launches(1)
     try:
-        wl.run()
+        wl.run(streams=1)           # single stream: with two half-jobs in flight a launch shares the chip with the other half's
         torch.cuda.synchronize(wl.device)
     finally:
         lib.codlad_probe_edge_launches(0)
@@ -346,6 +348,61 @@ def committed_traffic(cfg_name, precision):
     return d["hbm_bytes_per_launch"], f"profiles/{os.path.basename(finals[-1])} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {d['kernel']})"
 
 
+def decode_roofline(wl):
+    """Roofline object of the decoder tail (BASELINE configuration 5): HBM / latency-bound, the whole decode (CG graph, VQ,
+    IC decoder, ic_to_xyz) as one unit."""
+    t_dec = wl.timed(wl.run, 5)
+    n_atoms = sum(c * int(p["info"][0].numel()) for _s, c, p, _ca in wl.groups)
+    nbytes = sum(decode_bytes_per_structure(L, 0, 0) for L in wl.job.sample_lens) + 20 * n_atoms + \
+        16 * int(wl.csr[0][-1]) // 2
+    # SURVEY.md 8d prices this configuration against HBM; the tail is arithmetic- and latency-bound, so the same
+    # time is also priced against the fp32 rate: algorithmic FLOP of the decoder (reference vae_model.py:467-503:
+    # per directed CG edge and message block a 15 -> 40 filter, its envelope and a 40-wide multiply-add = 2 (15 40
+    # + 40 + 40) FLOP, four blocks; per residue the 40..53-wide dense layers, ~30 k MAC) and of the VQ scan
+    # (4096 codes x 8 FLOP per residue)
+    n_dir = int(wl.csr[0][-1])
+    alg_flop = 4 * 2 * (15 * 40 + 80) * n_dir + (2 * 30000 + 8 * 4096) * wl.job.n_nodes
+    return {"bound": "hbm", "achieved": nbytes / t_dec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / t_dec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "cg_graph + vq + dec_init/edge/dense/heads + ic_to_xyz (the whole decode; its largest kernel, "
+                      "dec_edge_kernel: per CG edge one sine / cosine, a 15 -> 40 filter on the f16 matrix pipe "
+                      "(split fp16) and a gathered 40-wide multiply-add)",
+            "launch_ms": t_dec * 1e3, "algorithmic_bytes_per_launch": nbytes,
+            "fp32_compute": {"algorithmic_flop_per_launch": alg_flop, "achieved_tflops": alg_flop / t_dec / 1e12,
+                             "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                             "frac": alg_flop / t_dec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                             "note": "algorithmic decoder + VQ FLOP / the same launch time / fp32 vector peak: "
+                                     "the tail is bound by latency and instruction issue, not by bytes"}}
+
+
+def recon_section(wl):
+    r = recon_from_atoms(wl)
+    return {"value": wl.n_structures / r["seconds"], "unit": "structures/s", "ms_per_step": r["seconds"] * 1e3,
+            "encoder_ms": r["encoder_seconds"] * 1e3, "frames": r["frames"], "atoms": r["atoms"],
+            "directed_atom_edges": r["directed_atom_edges"],
+            "note": "the same structures as test.py --experiment recon produces them: e3nn encoder on every frame's "
+                    "(synthetic) atoms + map_in, the frame's latent decoded once per ensemble member; `value` above "
+                    "is the decoder tail alone (BASELINE configuration 5 isolates the decoder / codebook kernels)"}
+
+
+def cfg5_section(device, steps=200, warmup=10):
+    """BASELINE configuration 5 (decoder only, 1 GPU) measured in the same process, for the default run's line: the same
+    timing rule as `--config cfg5` (CUDA-synchronised wall time over `steps` passes after `warmup`)."""
+    wl5 = Workload(device, "cfg5")
+    for _ in range(warmup):
+        wl5.run()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl5.run()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {"metric": "reconstructed all-atom structures/sec (cfg5: --experiment recon, decoder only)",
+            "value": wl5.n_structures * steps / dt, "unit": "structures/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "config": {"workload": wl5.cfg["what"], "structures_per_step": wl5.n_structures},
+            "roofline": decode_roofline(wl5), "recon_from_atoms": recon_section(wl5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +412,7 @@ def main():
                     help="BASELINE.json configuration (default cfg2, the one the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA timing of the same job")
+    ap.add_argument("--no-cfg5", action="store_true", help="cfg2 run: skip the appended decoder-only measurement (BASELINE configuration 5)")
     ap.add_argument("--precision", choices=["f16x3", "f16x4", "f32"], default="f16x3",
                     help="contraction mode: f16x3 (default) / f16x4 = fp32 operands split into fp16 hi+lo halves on "
                          "the f16 matrix pipe, 3 or 4 cross products per fp32 product, fp32 accumulation "
@@ -432,14 +490,7 @@ def main():
     if rank == 0 and world == 1:
         extra["prepass_ms"] = wl.timed(wl.prepass, 3) * 1e3     # share of ms_per_step spent before the first DDPM step
         if wl.decode_only:
-            r = recon_from_atoms(wl)
-            extra["recon_from_atoms"] = {
-                "value": wl.n_structures / r["seconds"], "unit": "structures/s", "ms_per_step": r["seconds"] * 1e3,
-                "encoder_ms": r["encoder_seconds"] * 1e3, "frames": r["frames"], "atoms": r["atoms"],
-                "directed_atom_edges": r["directed_atom_edges"],
-                "note": "the same structures as test.py --experiment recon produces them: e3nn encoder on every frame's "
-                        "(synthetic) atoms + map_in, the frame's latent decoded once per ensemble member; `value` above "
-                        "is the decoder tail alone (BASELINE configuration 5 isolates the decoder / codebook kernels)"}
+            extra["recon_from_atoms"] = recon_section(wl)
     if not wl.decode_only:
         kern = wl.time_dominant_kernel()          # back to back, alone on the chip
         insitu = probe_edge_kernels(wl)           # inside the job
@@ -447,11 +498,12 @@ def main():
         if world == 1 and args.precision != "f32" and not args.no_f32_leg:
             # the same job, same weights, contractions on the fp32 matrix instruction (IEEE fp32 products)
             wl.den.weights.set_precision("f32")
-            dt32 = timed_steps(1, 1)
+            F32_STEPS = 3
+            dt32 = timed_steps(1, F32_STEPS) / F32_STEPS
             k32 = wl.time_dominant_kernel(5)
             wl.den.weights.set_precision(args.precision)
             extra["f32_mfma"] = {"value": structs_per_step / dt32, "unit": "structures/s", "ms_per_step": dt32 * 1e3,
-                                 "launch_ms": k32["message"] * 1e3, "steps": 1, "warmup": 1,
+                                 "launch_ms": k32["message"] * 1e3, "steps": F32_STEPS, "warmup": 1,
                                  "note": "same job and weights with every contraction on v_mfma_f32_32x32x2_f32; "
                                          "roofline of that mode: algorithmic FLOP / launch / 157.3 TFLOP/s = "
                                          f"{2.0 * (384 * 128 + 128 * 128) * wl.n_edges / k32['message'] / 1e12 / FP32_MFMA_PEAK_TFLOPS:.3f}"
@@ -460,34 +512,15 @@ def main():
         value = structs_per_step * args.steps / dt
         terms = {"f16x3": 3, "f16x4": 4, "f32": 0}[args.precision]
         if wl.decode_only:
-            # HBM / latency-bound tail: the whole decode (CG graph, VQ, IC decoder, ic_to_xyz) as one unit
-            t_dec = wl.timed(wl.run, 5)
-            n_atoms = sum(c * int(p["info"][0].numel()) for _s, c, p, _ca in wl.groups)
-            nbytes = sum(decode_bytes_per_structure(L, 0, 0) for L in wl.job.sample_lens) + 20 * n_atoms + \
-                16 * int(wl.csr[0][-1]) // 2
-            # SURVEY.md 8d prices this configuration against HBM; the tail is arithmetic- and latency-bound, so the same
-            # time is also priced against the fp32 rate: algorithmic FLOP of the decoder (reference vae_model.py:467-503:
-            # per directed CG edge and message block a 15 -> 40 filter, its envelope and a 40-wide multiply-add = 2 (15 40
-            # + 40 + 40) FLOP, four blocks; per residue the 40..53-wide dense layers, ~30 k MAC) and of the VQ scan
-            # (4096 codes x 8 FLOP per residue)
-            n_dir = int(wl.csr[0][-1])
-            alg_flop = 4 * 2 * (15 * 40 + 80) * n_dir + (2 * 30000 + 8 * 4096) * wl.job.n_nodes
-            roofline = {"bound": "hbm", "achieved": nbytes / t_dec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": nbytes / t_dec / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "cg_graph + vq + dec_init/edge/dense/heads + ic_to_xyz (the whole decode; its largest kernel, "
-                                  "dec_edge_kernel: per CG edge one sine / cosine, a 15 -> 40 filter on the f16 matrix pipe "
-                                  "(split fp16) and a gathered 40-wide multiply-add)",
-                        "launch_ms": t_dec * 1e3, "algorithmic_bytes_per_launch": nbytes,
-                        "fp32_compute": {"algorithmic_flop_per_launch": alg_flop, "achieved_tflops": alg_flop / t_dec / 1e12,
-                                         "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                                         "frac": alg_flop / t_dec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                         "note": "algorithmic decoder + VQ FLOP / the same launch time / fp32 vector peak: "
-                                                 "the tail is bound by latency and instruction issue, not by bytes"}}
+            roofline = decode_roofline(wl)
         else:
             # dominant kernel: layers 1-2 of the encoder message MLP.  Algorithmic 2*(384*128 + 128*128) FLOP per
             # edge (reference protein_mpnn_utils.py:240-243; W3 runs in the node kernel); EXECUTED after the W1
             # split: two 128x128 contractions per edge, each product as `terms` f16 MFMA products.
-            alg = 2.0 * (384 * 128 + 128 * 128) * wl.n_edges
+            # The timed population (in_job_launch_ms["message"]) is the 5 non-hoisted message launches of a step: encoder
+            # layers 1 and 2 (65 536 algorithmic MAC per edge each) and the three decoder layers (81 920:
+            # protein_mpnn_utils.py:296-318, W1 is 512 -> 128 there), so a launch's algorithmic work is their mean.
+            alg = 2.0 * (2 * 65536 + 3 * 81920) / 5 * wl.n_edges
             exe = 2.0 * 2 * 128 * 128 * wl.n_edges
             traffic, traffic_src = committed_traffic(args.config, args.precision)
             if terms:
@@ -498,6 +531,10 @@ def main():
                 pipe = "fp32 matrix instruction (v_mfma_f32_32x32x2_f32)"
             roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                        # the same launch priced by SURVEY.md 8(d)'s ALGORITHMIC work (fp32 MACs of the reference's layers 1-2,
+                        # enc / dec mix above) instead of the matrix-pipe work executed for it (3 f16 products per fp32 product,
+                        # half the MACs after the W1 split): what fraction of the pipe's peak the USEFUL arithmetic amounts to
+                        "frac_algorithmic": alg / t_msg / 1e12 / peak,
                         "pipe": pipe,
                         "kernel": ("msg_kernel_h " if terms else "edge_kernel<false> ") + "(encoder message MLP, layers 1-2)",
                         "launch_ms": t_msg * 1e3,
@@ -534,6 +571,8 @@ def main():
             "roofline": roofline,
         }
         result.update(extra)
+        if world == 1 and args.config == "cfg2" and not args.no_cfg5:
+            result["cfg5"] = cfg5_section(device)       # BASELINE configuration 5 (the other 1-GPU configuration) in the same line
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(result), flush=True)

@@ -152,7 +152,7 @@ def lib():
     return _lib
 
 
-OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT, OPT_TP_CONV_VARIANT, OPT_EDGE_UPD_VARIANT = 0, 1, 3, 4, 5   # CODLAD_OPT_* of include/codlad_hip.h
+OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT, OPT_TP_CONV_VARIANT, OPT_EDGE_UPD_VARIANT, OPT_EDGE_CUS = 0, 1, 3, 4, 5, 6   # CODLAD_OPT_* of include/codlad_hip.h
 
 
 def set_option(option, value):

@@ -612,6 +612,10 @@ static int nodeq_max_tiles() { return option_or(CODLAD_OPT_NODEQ_MAX_TILES, "COD
 int dec_edge_variant() { return option_or(CODLAD_OPT_DEC_EDGE_VARIANT, "CODLAD_DEC_EDGE_VARIANT", 0); }
 int tp_conv_variant() { return option_or(CODLAD_OPT_TP_CONV_VARIANT, "CODLAD_TP_CONV_VARIANT", 0); }
 int edge_upd_variant() { return option_or(CODLAD_OPT_EDGE_UPD_VARIANT, "CODLAD_EDGE_UPD_VARIANT", 0); }
+int edge_cus() {
+    const int v = option_or(CODLAD_OPT_EDGE_CUS, "CODLAD_EDGE_CUS", 0);
+    return v > 0 && v < num_cu() ? v : num_cu();
+}
 
 // node_wide_kernels.hip
 void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st);

@@ -10,6 +10,7 @@
 
 void set_max_lds(const void *fn, size_t bytes);   // denoiser_kernels.hip: hipFuncSetAttribute, failure kept for the next check
 int num_cu();
+int edge_cus();     // persistent workgroups of an edge kernel: num_cu() unless CODLAD_OPT_EDGE_CUS says fewer
 
 // ---------------------------------------------------------------------------------------------
 // Edge kernels: one wave = one node = up to 64 neighbour columns (two 32-column passes).

@@ -489,7 +489,7 @@ static void launch_upd1_t(const EdgeArgs &ea, hipStream_t st) {
         attr_set = true;
     }
     const int groups = (ea.n_nodes + U1_NW - 1) / U1_NW;
-    dim3 grid(groups < num_cu() ? groups : num_cu()), block(U1_NW * 64);
+    dim3 grid(groups < edge_cus() ? groups : edge_cus()), block(U1_NW * 64);
     if (ea.E1 != nullptr) hipLaunchKernelGGL((upd1_kernel_h<true, TERMS>), grid, block, lds, st, ea);
     else hipLaunchKernelGGL((upd1_kernel_h<false, TERMS>), grid, block, lds, st, ea);
 }

@@ -117,7 +117,7 @@ static void launch_upd_t(const EdgeArgs &ea, hipStream_t st) {
         attr_set = true;
     }
     const int groups = (ea.n_nodes + NW - 1) / NW;
-    dim3 grid(groups < num_cu() ? groups : num_cu()), block(NW * 64);
+    dim3 grid(groups < edge_cus() ? groups : edge_cus()), block(NW * 64);
     if (ea.E1 != nullptr) hipLaunchKernelGGL((upd_kernel_h<NW, true, TERMS>), grid, block, lds, st, ea);
     else hipLaunchKernelGGL((upd_kernel_h<NW, false, TERMS>), grid, block, lds, st, ea);
 }

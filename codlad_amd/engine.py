@@ -8,6 +8,7 @@ k-NN graph and the initial edge embedding h_E0, which is computed once per struc
 once per denoiser call as the reference does (reference models/latent_model.py:208).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -68,9 +69,13 @@ class Structures:
 class Job:
     """Samples on structures: node tables + per-step workspace."""
 
-    def __init__(self, structures, sample_struct, device):
+    def __init__(self, structures, sample_struct, device, edge_state=None):
+        """edge_state: a [n_nodes, 64, 128] view to use as this job's edge state instead of a buffer of its own (the
+        parts of a split job live in their parent's)."""
         st = structures
         self.structures = st
+        self.device = device
+        self._parts = {}
         self.sample_struct = [int(s) for s in sample_struct]
         lens = [st.lens[f] for f in self.sample_struct]
         self.sample_lens = lens
@@ -93,7 +98,8 @@ class Job:
         self.hVenc = torch.empty(n, H, **f32)
         self.S = torch.empty(4, n, H, **f32)      # planes 1-3: per-half, per-lane-half partial sums of small jobs
         self.PQ = torch.empty(4, n, H, **f32)
-        self.hE = torch.empty(n, KNN, H, **f32)
+        self.hE = torch.empty(n, KNN, H, **f32) if edge_state is None else edge_state
+        assert tuple(self.hE.shape) == (n, KNN, H) and self.hE.is_contiguous()
         self.status = torch.zeros(1, dtype=torch.int32, device=device)   # sticky flags (CODLAD_STATUS_*)
         # non-empty 32-edge tiles {node, half}: small jobs deal the edge kernels' work out per tile
         halves = np.where(info[:, 2] > 32, 2, 1)
@@ -110,6 +116,23 @@ class Job:
 
     def workspace_bytes(self):
         return 4 * (self.hV.numel() * 2 + self.S.numel() + self.PQ.numel() + self.hE.numel())
+
+    def parts(self, k=2):
+        """This job's samples dealt alternately into k independent jobs (the same mix of lengths in each) -> [(job, node
+        indices of its samples in this job)].  The parts keep their edge state in slices of this job's buffer (32 KB per
+        node: nothing else of a workspace is large), so a job and its parts are never in flight together."""
+        if k not in self._parts:
+            subs, start = [], 0
+            for p in range(k):
+                members = list(range(p, len(self.sample_struct), k))
+                n = int(sum(self.sample_lens[m] for m in members))
+                sub = Job(self.structures, [self.sample_struct[m] for m in members], self.device,
+                          edge_state=self.hE[start:start + n])
+                idx = np.concatenate([np.arange(self.sample_off[m], self.sample_off[m + 1]) for m in members])
+                subs.append((sub, torch.from_numpy(idx).to(self.device)))
+                start += n
+            self._parts[k] = subs
+        return self._parts[k]
 
 
 class Denoiser:
@@ -246,14 +269,33 @@ class Denoiser:
             self.check_status(job)
         return out
 
-    def sample(self, job, x_T, noise, tables, check=True, coef=None):
+    # A job of this many nodes or more runs as two half-jobs on two HIP streams (round 4; measured on BASELINE
+    # configuration 2, 35 400 nodes: +3 %): the node kernel of such a job occupies ~140 of the 256 CUs and every kernel
+    # has a tail, which the other half's edge kernels fill.  Every unit's result is independent of what shares its job
+    # (tests hold that to the bit), so the split changes nothing but the schedule.  Three and more parts lose.
+    SPLIT_MIN_NODES = int(os.environ.get("CODLAD_SAMPLE_SPLIT_MIN_NODES", 16384))
+
+    def sample(self, job, x_T, noise, tables, check=True, coef=None, streams=None):
         """Full ancestral loop.  x_T [n_nodes,3]; noise [T,n_nodes,3] in loop order (first entry
         is used at step T-1); tables = diffusion_and_flow.schedule.Tables.  Returns x_0.
-        check: after the loop, synchronise and raise if any step's output was not finite."""
+        check: after the loop, synchronise and raise if any step's output was not finite.
+        coef: the [T, 8] step table when it is not the default sampler's (SpacedDiffusion.coefficients).
+        streams: 1 = the whole job on the current stream; 2 = two half-jobs on two streams; None = 2 from
+        SPLIT_MIN_NODES nodes up (and at least two samples)."""
         _require_cuda(x_T, "x_T")
         _require_cuda(noise, "noise")
         T = tables.num_timesteps
         assert noise.shape == (T, job.n_nodes, 3) and x_T.shape == (job.n_nodes, 3)
+        if streams is None:
+            streams = 2 if job.n_nodes >= self.SPLIT_MIN_NODES and len(job.sample_struct) >= 2 else 1
+        if streams > 1:
+            parts = job.parts(streams)
+            outs = self.sample_many([p for p, _i in parts], [x_T[i] for _p, i in parts], [noise[:, i] for _p, i in parts],
+                                    tables, check=check, coef=coef)
+            x0 = torch.empty(job.n_nodes, 3, dtype=torch.float32, device=self.device)
+            for (_p, i), o in zip(parts, outs):
+                x0[i] = o
+            return x0
         coef = tables.step_coefficients() if coef is None else coef
         fixed_var = bool(int(coef[0, 7]) & 2)
         if self.weights.out_dim != (3 if fixed_var else 6):
@@ -277,7 +319,7 @@ class Denoiser:
             self.check_status(job)
         return x
 
-    def sample_many(self, jobs, x_Ts, noises, tables, check=True):
+    def sample_many(self, jobs, x_Ts, noises, tables, check=True, coef=None):
         """Several independent jobs at once, each on its own HIP stream: the node kernel of a 35 000-node job occupies 139 of
         the 256 CUs and every kernel has a tail - with a second job in flight another job's edge kernels run there (two
         half-jobs of BASELINE configuration 2: 1.03 x; more than two parts lose).  Every job carries its
@@ -294,7 +336,7 @@ class Denoiser:
         for job, x_T, noise, st in zip(jobs, x_Ts, noises, self._streams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                outs.append(self.sample(job, x_T, noise, tables, check=False))
+                outs.append(self.sample(job, x_T, noise, tables, check=False, coef=coef, streams=1))
         for st in self._streams[:len(jobs)]:
             cur.wait_stream(st)
         if check:

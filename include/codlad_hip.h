@@ -395,6 +395,7 @@ int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t 
 #define CODLAD_OPT_DEC_EDGE_VARIANT 3
 #define CODLAD_OPT_TP_CONV_VARIANT 4
 #define CODLAD_OPT_EDGE_UPD_VARIANT 5
+#define CODLAD_OPT_EDGE_CUS 6
 #define CODLAD_N_OPTIONS 8
 int codlad_set_option(int option, int value);
 

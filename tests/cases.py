@@ -48,7 +48,13 @@ E2E_CASES = {
     # name -> (n_cg, n_frames, seed, T, vae_type, dataname)
     "PED_N6_L46_B2_T10": (46, 2, 41, 10, "N6", "PED"),
     "PED_N6_L87_B2_T100": (87, 2, 42, 100, "N6", "PED"),
+    # the angle decoders end to end (round 4): sequences with TPO / SEP, as the K3 / K4 sets have them
+    "PDB_K3_L60_B2_T10": (60, 2, 43, 10, "K3", "PDB"),
+    "Atlas_K4_L129_B1_T10": (129, 1, 44, 10, "K4", "Atlas"),
 }
+# VQ codes that differ from the reference's on the committed goldens, per case and contraction mode: none today.  A
+# near-tie that a later change of rounding flips has to be listed here by name, with its margin, to be accepted.
+E2E_EXPECTED_FLIPS = {}
 
 
 # Weight sets that probe the envelope of the split-fp16 contraction modes (f16x3 / f16x4): every case is a
@@ -267,3 +273,10 @@ SAMPLER_BRANCH_CASES = {
     "fixed_small_L87_T10": (87, 1, 75, 10, dict(learn_sigma=False, sigma_small=True), False, True),
     "fixed_small_xstart_clip_L46_T10": (46, 1, 76, 10, dict(learn_sigma=False, sigma_small=True, predict_xstart=True), True, True),
 }
+# GPU tolerance of a case's trajectory against the reference's (default 2e-5).  xstart_clip: an UNTRAINED x_0-predictor under
+# clip_denoised is an unstable map - a deviation doubles per step (measured on MI355X, identically in the f16x3 mode and in the
+# IEEE-fp32 matrix mode: 7.9e-6 after step 1, 3.5e-5, 4.3e-5, 8.9e-5, 6.6e-5, 2.0e-4, 4.6e-4, 1.1e-3, 2.3e-3, 1.1e-3), so the
+# case bounds the first steps tightly, the end loosely, and holds the two contraction modes to each other at 2e-5.
+# eps_clip: the clamp is active on most coordinates from the middle of the loop on; the deviation grows from 4e-6 to 3.3e-5
+# (f16x3) / 4.0e-5 (IEEE-fp32 matrix mode) over the ten steps.
+SAMPLER_BRANCH_TOL = {"xstart_clip_L46_T10": 5e-3, "eps_clip_L87_T10": 1e-4}

@@ -53,8 +53,11 @@ def test_flow_model_forward_and_fixed_grid_sampling(fsd, name, precision):
     for method in ("euler", "rk4"):
         y = ode.odeint(f, xd, ts, method=method)[-1]
         assert rel_err(y.view(B, L, 3), gold[method]) < 2e-5, method
-    with pytest.raises(ValueError, match="diffusion model"):           # the DDPM loop refuses a velocity model
-        den.sample(job, xd, torch.zeros(10, B * L, 3, device=DEV), None if False else type("T", (), {"num_timesteps": 10})())
+    # the DDPM loop of the default (learned-variance) sampler refuses a 3-output model; a fixed-variance sampler takes one
+    # (tests/test_dropin_api.py::test_sampler_branches_like_the_reference)
+    from codlad_amd.diffusion_and_flow.schedule import Tables, named_betas, space_timesteps
+    with pytest.raises(ValueError, match="fixed-variance sampler"):
+        den.sample(job, xd, torch.zeros(10, B * L, 3, device=DEV), Tables(named_betas("linear", 1000), space_timesteps(1000, "10")))
 
 
 def test_dropin_model_and_run_sampling_call_shape(fsd):

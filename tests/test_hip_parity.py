@@ -507,13 +507,13 @@ def allowed_code_flips(lat_mine, lat_ref, codebook):
 
 @pytest.mark.parametrize("name", list(cases.E2E_CASES))
 def test_end_to_end(den, sd, name):
-    """noise -> xyz on the GPU vs the reference CPU path.  A VQ code may differ from the reference's only where
-    the OBSERVED latent deviation of that residue can bridge the reference's own top-2 margin
-    (allowed_code_flips); every frame without such a flip must agree to RMSD <= 1e-4 A, and at least one frame
-    must be flip-free, so the coordinate comparison always runs."""
+    """noise -> xyz on the GPU vs the reference CPU path (N6 and the two angle decoders).  A VQ code may differ from
+    the reference's only where the OBSERVED latent deviation of that residue can bridge the reference's own top-2 margin
+    (allowed_code_flips) AND the case lists that near-tie by name (cases.E2E_EXPECTED_FLIPS: none on the committed
+    goldens); then EVERY frame's internal coordinates and Cartesian coordinates are compared."""
     L, B, seed, T, vae_type, dataname = cases.E2E_CASES[name]
     gold = np.load(cases.npz_path(f"g7_e2e_{name}"))
-    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+    prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed, phospho=vae_type != "N6")
     z, eps = cases.loop_noise(T, B, L, seed)
     st = structures_of(den, prot)
     job = den.make_job(st, list(range(B)))
@@ -527,20 +527,35 @@ def test_end_to_end(den, sd, name):
     allowed, ref_idx, margin = allowed_code_flips(lat.cpu(), lat_ref, odec.codebook_of(vsd))
     assert torch.equal(ref_idx, torch.from_numpy(gold["idx"]).reshape(-1))   # the golden's own codes, recomputed
     differ = idx.cpu() != ref_idx
-    n_flip = int(differ.sum())
     assert not bool((differ & ~allowed).any()), \
         f"{int((differ & ~allowed).sum())} VQ codes differ where the latent deviation cannot explain it " \
         f"(smallest such margin {float(margin[differ & ~allowed].min()):.3e})"
-    assert n_flip <= 2, f"{n_flip} near-tie code flips in {B * L} residues"
+    expected = sorted(cases.E2E_EXPECTED_FLIPS.get((name, den.weights.precision), []))
+    assert differ.nonzero().flatten().tolist() == expected, \
+        f"VQ codes of residues {differ.nonzero().flatten().tolist()} differ from the reference's (margins " \
+        f"{margin[differ].tolist()}); expected {expected}"
+    # with no unexpected flip every frame decodes from the reference's own codes: all of them are compared
     ic = dec.ic_decode(zq, batch["CG_nxyz"][:, 0].long(), batch["CG_nxyz"][:, 1:], batch["CG_nbr_list"])
-    xyz = dec.ic_to_xyz(batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)[:, :, 1:].to(DEV),
-                        ic.view(B, L, 13, 3), prot["info"])
-    clean = ~differ.view(B, L).any(dim=1)                                    # frames without a flipped code
-    assert bool(clean.any()), "every frame has a flipped VQ code: coordinates could not be compared"
-    d2 = ((xyz.cpu() - torch.from_numpy(gold["xyz"])) ** 2).sum(-1)          # [B, n_atoms]
-    rmsd = d2[clean].mean().sqrt()
-    assert float(rmsd) < 1e-4, float(rmsd)
-    print(f"{name}: {n_flip} near-tie code flips, {int(clean.sum())}/{B} frames compared, RMSD {float(rmsd):.2e} A")
+    clean = ~differ.view(B, L).any(dim=1)
+    assert int(clean.sum()) == B - len({r // L for r in expected})
+    ic_ref = torch.from_numpy(gold["ic_recon"]).reshape(B, L, 13, 3)
+    assert rel_err(ic.view(B, L, 13, 3).cpu()[clean], ic_ref[clean]) < 2e-5
+    og = batch["OG_CG_nxyz"].reshape(-1, L + 2, 4)
+    xyz = dec.ic_to_xyz(og[:, :, 1:].to(DEV), ic.view(B, L, 13, 3), prot["info"])
+    gx = torch.from_numpy(gold["xyz"])
+    rmsd = ((xyz.cpu() - gx) ** 2).sum(-1)[clean].mean().sqrt()
+    # N6: RMSD <= 1e-4 A (north_star).  The angle decoders with untrained weights place some atoms from near-collinear
+    # triplets, where ic -> xyz is ill-conditioned (the reference's own fp32 coordinates are up to ~1e-3 A from an fp64
+    # run of the same placements): there the coordinates must be about as close to the fp64 placement of the REFERENCE's
+    # internal coordinates as the reference's own fp32 result is - the criterion of test_ic_decode_and_xyz.
+    if vae_type == "N6":
+        assert float(rmsd) < 1e-4, float(rmsd)
+    else:
+        x64 = odec.ic_to_xyz(og.double(), ic_ref.double(), prot["info"])
+        ref_err = float((gx.double() - x64)[clean].abs().max())
+        my_err = float((xyz.cpu().double() - x64)[clean].abs().max())
+        assert my_err < 4 * ref_err + 1e-4, (my_err, ref_err)
+    print(f"{name}: no code flips, {int(clean.sum())}/{B} frames compared, RMSD {float(rmsd):.2e} A")
 
 
 def test_random_ragged_jobs_against_oracle_and_between_modes(sd):

@@ -309,6 +309,12 @@ def test_hot_edge_kernels_keep_their_register_budget():
         r = table[name]
         assert r["VGPRs"] <= 256 and r["Occupancy"] == 2, (name, r)
         assert r["ScratchSize"] <= scratch, (name, r)
+    # the one-wave-per-SIMD edge update (round 4) has the whole 512-register file and must not touch scratch at all: a
+    # scratch access counts in vmcnt and gets an s_waitcnt vmcnt(0), which waits for the tile prefetch in flight
+    for name in ("_Z13upd1_kernel_hILb0ELi3EEv8EdgeArgs", "_Z13upd1_kernel_hILb1ELi3EEv8EdgeArgs",
+                 "_Z13upd1_kernel_hILb0ELi4EEv8EdgeArgs", "_Z13upd1_kernel_hILb1ELi4EEv8EdgeArgs"):
+        r = table[name]
+        assert r["Occupancy"] == 1 and r["ScratchSize"] == 0, (name, r)
 
 
 @pytest.mark.parametrize("name", list(cases.INFO_CASES))

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from codlad_amd import _lib  # noqa: E402
 
-OPTS = {"NODEQ_MAX_TILES": 0, "EDGE_TILE_MAX_NODES": 1, "DEC_EDGE_VARIANT": 3, "TP_CONV_VARIANT": 4, "EDGE_UPD_VARIANT": 5, "EDGE_MSG_VARIANT": 6}
+OPTS = {"NODEQ_MAX_TILES": 0, "EDGE_TILE_MAX_NODES": 1, "DEC_EDGE_VARIANT": 3, "TP_CONV_VARIANT": 4, "EDGE_UPD_VARIANT": 5, "EDGE_CUS": 6}
 
 
 def main():
@@ -23,21 +23,22 @@ def main():
     ap.add_argument("settings", nargs="+", help="NAME=VALUE[,NAME=VALUE...] per arm")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--streams", type=int, default=None, help="1: the whole job on one stream; default: as the product runs it")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     dev = torch.device("cuda", 0)
     wl = bench.Workload(dev, args.config)
-    wl.run()
+    wl.run(streams=args.streams)
     torch.cuda.synchronize()
     for rnd in range(args.rounds):
         for arm in args.settings:
             pairs = [kv.split("=") for kv in arm.split(",")]
             for k, v in pairs:
                 _lib.set_option(OPTS[k], int(v))
-            wl.run()
+            wl.run(streams=args.streams)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            wl.run()
+            wl.run(streams=args.streams)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             line = f"{arm:40s} {wl.n_structures / dt:8.1f} structures/s"

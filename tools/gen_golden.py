@@ -530,7 +530,7 @@ def g7_end_to_end(ref, model):
     os.chdir(ref["root"])
     try:
         for name, (L, B, seed, T, vae_type, dataname) in cases.E2E_CASES.items():
-            prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed)
+            prot, batch, _x, _t, mask = cases.denoiser_inputs(L, B, seed, phospho=vae_type != "N6")
             z, eps = cases.loop_noise(T, B, L, seed)
             traj = run_loop(ref, model, T, z, eps, mask, batch)
             samples = traj[-1]
