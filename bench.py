@@ -412,6 +412,9 @@ def main():
                     help="BASELINE.json configuration (default cfg2, the one the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA timing of the same job")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="1: the whole job on one HIP stream (kernel traces / counter passes, where a kernel's duration must be "
+                         "its own); default: as the product runs it (a large job = two half-jobs on two streams)")
     ap.add_argument("--no-cfg5", action="store_true", help="cfg2 run: skip the appended decoder-only measurement (BASELINE configuration 5)")
     ap.add_argument("--precision", choices=["f16x3", "f16x4", "f32"], default="f16x3",
                     help="contraction mode: f16x3 (default) / f16x4 = fp32 operands split into fp16 hi+lo halves on "
@@ -461,7 +464,7 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        xyz, idx = wl.run()
+        xyz, idx = wl.run(streams=args.streams)
         if world > 1:
             from codlad_amd.parallel import gather_coordinates
             gather_coordinates(xyz, world)
@@ -567,7 +570,11 @@ def main():
                                        "vectors + CG graph + DDPM loop + VQ + IC decode + ic_to_xyz"
                                        + (" + all-gather of coordinates" if world > 1 else ""),
                        "parallelism": (f"units sharded x{world} (LPT), no data-path collective" if strong
-                                       else f"replicas x{world}")},
+                                       else f"replicas x{world}"),
+                       "streams": ("two half-jobs on two HIP streams per GPU (codlad_amd.engine.Denoiser.sample, jobs of "
+                                   ">= 8 192 nodes); the roofline's per-launch times come from a separate single-stream pass"
+                                   if args.streams is None and not wl.decode_only and wl.job.n_nodes >= wl.den.SPLIT_MIN_NODES
+                                   else "one HIP stream")},
             "roofline": roofline,
         }
         result.update(extra)

@@ -270,10 +270,12 @@ class Denoiser:
         return out
 
     # A job of this many nodes or more runs as two half-jobs on two HIP streams (round 4; measured on BASELINE
-    # configuration 2, 35 400 nodes: +3 %): the node kernel of such a job occupies ~140 of the 256 CUs and every kernel
+    # configuration 2, 35 400 nodes: +2.5 %): the node kernel of such a job occupies ~140 of the 256 CUs and every kernel
     # has a tail, which the other half's edge kernels fill.  Every unit's result is independent of what shares its job
     # (tests hold that to the bit), so the split changes nothing but the schedule.  Three and more parts lose.
-    SPLIT_MIN_NODES = int(os.environ.get("CODLAD_SAMPLE_SPLIT_MIN_NODES", 16384))
+    # Where it starts to pay (tools/mall_probe.py, structures of 87 residues, one box): 34 800 nodes +2.0 %, 17 400 +2.1 %,
+    # 8 700 +9.6 % (each half then takes the small-job node kernel), 5 220 -1.9 %, 3 480 +5.5 %, 1 740 -8 %.
+    SPLIT_MIN_NODES = int(os.environ.get("CODLAD_SAMPLE_SPLIT_MIN_NODES", 8192))
 
     def sample(self, job, x_T, noise, tables, check=True, coef=None, streams=None):
         """Full ancestral loop.  x_T [n_nodes,3]; noise [T,n_nodes,3] in loop order (first entry

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 11
+#define CODLAD_ABI_VERSION 12
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -389,7 +389,11 @@ int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t 
  *                                NOT bit-identical to each other (both within the decoder's parity tolerance)
  *   CODLAD_OPT_TP_CONV_VARIANT   codlad_tp_conv with group = 64: 0 = fc.0 / fc.3 on the f16 matrix pipe (split fp16,
  *                                fp32-equivalent; a wave per receiving node, 32 edges per step); 1 = the scalar-operand
- *                                kernel that also serves groups 1 and 16.  Not bit-identical to each other either */
+ *                                kernel that also serves groups 1 and 16.  Not bit-identical to each other either
+ *   CODLAD_OPT_EDGE_UPD_VARIANT  edge update of large jobs: 0 = two waves per SIMD (upd_kernel_h); 1 = one wave per SIMD with
+ *                                the next tile prefetched (upd1_kernel_h) where nearly every node has two 32-edge tiles;
+ *                                2 = that kernel for every job.  Bit-identical; same speed on MI355X (profiles/r04_upd1_*)
+ *   CODLAD_OPT_EDGE_CUS          persistent workgroups of the per-node edge kernels (0 / >= CU count: one per CU) */
 #define CODLAD_OPT_NODEQ_MAX_TILES 0
 #define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
 #define CODLAD_OPT_DEC_EDGE_VARIANT 3

@@ -13,7 +13,7 @@ for rep in range(2):
         if lib:
             env["CODLAD_HIP_LIB"] = os.path.abspath(lib)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                              "--no-f32-leg"], env=env, capture_output=True, text=True).stdout
+                              "--no-f32-leg", "--no-cfg5"], env=env, capture_output=True, text=True).stdout
         d = json.loads(out.strip().splitlines()[-1])
         print(f"{os.path.basename(lib) if lib else 'default':28s} {d['value']:7.1f} structures/s   msg {d['roofline']['launch_ms']:.4f} ms   "
               f"upd {d['roofline']['edge_update_launch_ms']:.4f} ms", flush=True)

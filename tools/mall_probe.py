@@ -1,4 +1,5 @@
-"""Does a job whose edge state fits the 256 MB Infinity Cache run faster per node?  100-step loops over n structures of
+"""Does a job whose edge state fits the 256 MB Infinity Cache run faster per node, and from what size on do two half-jobs on two
+streams pay?  100-step loops over n structures of
 L = 87 (K = 64: 32 KB of edge state per node), one job at a time: ns per node and step.
     [CODLAD_HIP_LIB=variants/libcodlad_nont.so] python tools/mall_probe.py"""
 import os
@@ -24,13 +25,15 @@ for n_struct in (400, 200, 100, 60, 40, 20):
     n = job.n_nodes
     x = synth.gaussian((n, 3), 3).to(DEV)
     eps = synth.gaussian((T, n, 3), 4).to(DEV)
-    den.sample(job, x, eps, tables)
-    torch.cuda.synchronize()
-    reps = max(1, 400 // n_struct)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        den.sample(job, x, eps, tables)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print(f"{n_struct:4d} structures  {n:6d} nodes  edge state {n * 32768 / 2**20:7.1f} MiB   {dt * 1e3:8.2f} ms per job   "
-          f"{dt / T / n * 1e9:7.2f} ns per node-step   {n_struct / dt:7.1f} structures/s", flush=True)
+    line = f"{n_struct:4d} structures  {n:6d} nodes  edge state {n * 32768 / 2**20:7.1f} MiB"
+    for streams in (1, 2):
+        den.sample(job, x, eps, tables, streams=streams)
+        torch.cuda.synchronize()
+        reps = max(1, 400 // n_struct)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            den.sample(job, x, eps, tables, streams=streams)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        line += f"   {streams} stream(s): {dt * 1e3:8.2f} ms  {dt / T / n * 1e9:7.2f} ns per node-step  {n_struct / dt:7.1f} structures/s"
+    print(line, flush=True)

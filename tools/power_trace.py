@@ -51,4 +51,4 @@ if __name__ == "__main__":
     print("\n".join("#   " + l for l in cap.splitlines() if "Power" in l))
     trace("idle, 2 s", None, 2.0)
     trace("bench.py cfg2, 6 jobs", [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1",
-                                    "--no-cpu-baseline", "--no-f32-leg"])
+                                    "--no-cpu-baseline", "--no-f32-leg", "--no-cfg5"])

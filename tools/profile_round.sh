@@ -6,21 +6,24 @@ TAG=${1:-r02_final}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py --steps 3 --warmup 1 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
-echo "bench cfg2 (f16x3 + f32 leg + cpu baseline) done"
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --precision f16x4 > $OUT/bench_cfg2_f16x4.json 2>/dev/null
+echo "bench cfg2 (f16x3 + f32 leg + cfg5 section + cpu baseline) done"
+python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-leg --no-cfg5 --streams 1 > $OUT/bench_cfg2_one_stream.json 2>/dev/null
+echo "bench cfg2 on one stream done"
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-cfg5 --precision f16x4 > $OUT/bench_cfg2_f16x4.json 2>/dev/null
 for c in cfg3 cfg4share; do python3 bench.py --steps 2 --warmup 1 --config $c > $OUT/bench_$c.json 2>/dev/null; echo "bench $c done"; done
 python3 bench.py --config cfg5 > $OUT/bench_cfg5.json 2>/dev/null; echo "bench cfg5 done"
+python3 tools/two_stream_probe.py 2 > $OUT/two_stream_probe.txt 2>/dev/null
 python3 tools/small_job_latency.py > $OUT/small_jobs.txt 2>/dev/null
 CODLAD_EDGE_TILE_MAX_NODES=0 CODLAD_NODEQ_MAX_TILES=0 python3 tools/small_job_latency.py > $OUT/small_jobs_round1_kernels.txt 2>/dev/null
 echo "small jobs done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg > $OUT/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg --no-cfg5 --streams 1 > $OUT/trace.log 2>&1
 python3 tools/kernel_stats.py $OUT/trace > $OUT/kernel_stats.txt
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
 echo "trace done"
 i=0
 while read -r SET; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg > $OUT/pmc$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg --no-cfg5 --streams 1 > $OUT/pmc$i.log 2>&1
   python3 tools/pmc_summary.py $OUT/pmc$i > $OUT/pmc$i.txt
   echo "pmc pass $i done: $SET"
 done <<'SETS'

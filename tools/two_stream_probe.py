@@ -29,7 +29,7 @@ def timed(fn, n=2):
 
 
 def whole():
-    return wl.den.sample(wl.job, wl.x_T, wl.noise, wl.tables, check=False)
+    return wl.den.sample(wl.job, wl.x_T, wl.noise, wl.tables, check=False, streams=1)
 
 
 t_whole = timed(whole)
@@ -51,7 +51,7 @@ for P in parts_list:
         for job, x_T, noise, st in jobs:
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                wl.den.sample(job, x_T, noise, wl.tables, check=False)
+                wl.den.sample(job, x_T, noise, wl.tables, check=False, streams=1)
         for _job, _x, _n, st in jobs:
             cur.wait_stream(st)
 
