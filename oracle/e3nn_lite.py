@@ -1,4 +1,7 @@
-"""TEST INFRASTRUCTURE (CPU oracle) - PARITY UNPINNED.
+"""TEST INFRASTRUCTURE (CPU oracle) - the e3nn PRIMITIVES are PARITY UNPINNED; the encoder / prior built on them are pinned
+by the reference's own forward passes (goldens g15: tools/gen_golden.py binds e3nn.o3 to adapters over the primitives below
+and runs the reference's e3nnPrior / e3nnEncoder / TensorProductConvLayer; tests/test_oracle_vs_golden.py holds
+prior_forward / encoder_forward / tp_conv_layer to them).
 
 Restatement of the pieces of e3nn 0.5.1 (requirements.txt:6 of the reference; the package is NOT installed here and
 is not vendored by the reference) that the reference's encoder / prior use, from e3nn's published definitions:

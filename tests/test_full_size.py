@@ -97,6 +97,15 @@ def test_cfg2_ped_n6_full_size():
     whole = check_job(cfg, units, n_shards=2, shards_to_run=[0, 1], oracle_units=[0])
     # ensemble members of one frame differ (different noise) but share one structure
     assert not torch.equal(whole[0][0], whole[1][0])
+    # the one-wave-per-SIMD edge update (round 4) and a single stream instead of two half-jobs: the same bits at full size
+    from codlad_amd import _lib
+    _lib.set_option(_lib.OPT_EDGE_UPD_VARIANT, 1)
+    try:
+        other = cfg.run_units(units)
+    finally:
+        _lib.set_option(_lib.OPT_EDGE_UPD_VARIANT, 0)
+    for u in units:
+        assert pipeline.same(whole[u], other[u]), u
 
 
 def test_cfg5_recon_decoder_only_full_size():
