@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void k(int iters, const u32x4 *wg, float *o
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { in.b[b][q] = 0.125f * acc.b[b][q] + in.b[(b + 1) & 3][(q + 5) & 15] * 0.5f; acc.b[b][q] = 0.f; }
+                for (int q = 0; q < 16; ++q) { in.b[b][q] = 1e-4f * acc.b[b][q] + in.b[(b + 1) & 3][(q + 5) & 15]; acc.b[b][q] = 0.f; }
         }
         for (int b = 0; b < 4; ++b)
             for (int q = 0; q < 16; ++q) r += in.b[b][q];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void k(int iters, const u32x4 *wg, float *o
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { in.a[b][c][q] = 0.125f * acc.a[b][c][q] + in.a[(b + 1) & 7][c][(q + 1) & 3] * 0.5f; acc.a[b][c][q] = 0.f; }
+                    for (int q = 0; q < 4; ++q) { in.a[b][c][q] = 1e-4f * acc.a[b][c][q] + in.a[(b + 1) & 7][c][(q + 1) & 3]; acc.a[b][c][q] = 0.f; }
         }
         for (int b = 0; b < 8; ++b)
             for (int c = 0; c < 2; ++c)
