@@ -65,16 +65,7 @@ DEV void qtile_request(QTile &t, const float *block, int e, int h) {
         const char *pb = p + bo * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#ifdef U1_DBG_VISIBLE
-            t.q[bo][q] = *reinterpret_cast<const f32x4 *>(pb + q * 1024);
-            continue;
-#endif
-#ifdef U1_DBG_NONT
-            constexpr bool nt = false;
-#else
-            constexpr bool nt = STREAM;
-#endif
-            if (nt) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=a"(t.q[bo][q]) : "v"(pb), "n"(q * 1024) : "memory");
+            if (STREAM) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=a"(t.q[bo][q]) : "v"(pb), "n"(q * 1024) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(t.q[bo][q]) : "v"(pb), "n"(q * 1024) : "memory");
         }
     }
@@ -199,22 +190,6 @@ DEV void layer1_residual(Tile &acc, Tile &x, const QTile &xn, const u32x4 *wl, c
         }
     }
 }
-
-#ifdef U1_DBG_ECHO
-DEV void qtile_echo(Tile &t, const QTile &in) {
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const u32x4 hb = __builtin_bit_cast(u32x4, in.q[bo][2 * s]), lb = __builtin_bit_cast(u32x4, in.q[bo][2 * s + 1]);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t.b[bo][8 * s + 2 * p]) : "v"(hb[p]), "v"(lb[p]));
-                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(t.b[bo][8 * s + 2 * p + 1]) : "v"(hb[p]), "v"(lb[p]));
-            }
-        }
-}
-#endif
 
 template <bool HOISTED, int TERMS>
 __global__ __launch_bounds__(U1_NW * 64, 1) void upd1_kernel_h(EdgeArgs a) {
@@ -370,24 +345,13 @@ __global__ __launch_bounds__(U1_NW * 64, 1) void upd1_kernel_h(EdgeArgs a) {
         const float *c_b2 = c_base + lds_off, *c_b3 = c_b2 + HD;
         U1_MARK(0);                 // advance / loop overhead
         w = walk_issue();
-#ifdef U1_DBG_WAIT0
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         tile_add_row(acc, reinterpret_cast<const float *>(Pslots + parity * 64) + lds_off, h);
         // the tile's Q rows have been used, so its stored rows (requested before them) are in xn; nothing that reads xn
         // may move above this point
-#ifdef U1_DBG_WAIT
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_sched_barrier(0);
         U1_MARK(1);                 // P + Q (the wait for the tile's rows)
         // layer 1; the residual enters layer 3's accumulator as (hi + lo) * 2^E + b13 * 2^E
-#ifdef U1_DBG_ECHO
-        qtile_echo(x, xn);
-        if (false) {
-#else
         if (HOISTED) {
-#endif
 #pragma unroll
             for (int bo = 0; bo < 4; ++bo) acc.b[bo] += e1n.b[bo];
             qtile_unsplit_scale_add_row(x, xn, a.res_scale, c_b3, h);
@@ -410,10 +374,6 @@ __global__ __launch_bounds__(U1_NW * 64, 1) void upd1_kernel_h(EdgeArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         U1_MARK(3);                 // walk loads taken, rows requested
         tile_load_row(t2, c_b2, h);
-#ifdef U1_DBG_ECHO
-        if (false) {}
-        else
-#endif
         if (!(U1_ABLATE & 1)) gemm128_h_lds<TERMS, true, false, false, U1_AHEAD>(t2, acc, w2, lane, a.gelu_a);   // layer 2 on GELU(layer 1)
         else { for (int bo = 0; bo < 4; ++bo) t2.b[bo] += acc.b[bo]; }
         __builtin_amdgcn_sched_barrier(0);
@@ -435,10 +395,6 @@ __global__ __launch_bounds__(U1_NW * 64, 1) void upd1_kernel_h(EdgeArgs a) {
             int lds_off = 0;
             asm volatile("" : "+v"(lds_off));
             const float *c_modA = c_base + lds_off + 2 * HD, *c_modB = c_modA + HD;
-#ifdef U1_DBG_ECHO
-            if (false) {}
-            else
-#endif
             if (!(U1_ABLATE & 1)) gemm128_h_lds<TERMS, true, false, false, U1_AHEAD>(x, t2, w3, lane, a.gelu_b);   // layer 3 on GELU(layer 2)
             else { for (int bo = 0; bo < 4; ++bo) x.b[bo] += t2.b[bo]; }
             __builtin_amdgcn_sched_barrier(0);
@@ -446,12 +402,7 @@ __global__ __launch_bounds__(U1_NW * 64, 1) void upd1_kernel_h(EdgeArgs a) {
             issue_q();
             __builtin_amdgcn_sched_barrier(0);
             U1_MARK(6);             // Q rows requested
-#ifdef U1_DBG_ECHO
-            tile_presplit(x);
-            if (false) {
-#else
             if (!(U1_ABLATE & 1)) {
-#endif
                 tile_layernorm_affine(x, a.ln_eps, c_modA, c_modB, h);
                 tile_presplit(x);
             }

@@ -352,3 +352,35 @@ def test_pdb_writer_round_trips_through_the_reader(tmp_path):
     assert text.count("MODEL ") == 3 and text.count("ENDMDL") == 3
     info, _ = info_from_residues(["GLY"] + r_names + ["GLY"], [["N", "CA", "C", "O"]] + r_atoms + [["N", "CA", "C", "O"]])
     assert info[0].numel() == n_atoms
+
+
+def test_job_parts_deal_the_samples_and_share_the_edge_state():
+    """engine.Job.parts (round 4: a large job runs as two half-jobs on two HIP streams): the samples are dealt alternately,
+    every node of the job belongs to exactly one part, a part's tables are those of a job built from its samples alone, and
+    the parts keep their edge state in disjoint slices of the parent's buffer (no second 32 KB per node)."""
+    from codlad_amd.engine import Job, Structures
+    lens = [7, 40, 33, 64, 12, 70, 5]
+    prots = [synth.make_protein(L, 700 + i, n_frames=1) for i, L in enumerate(lens)]
+    st = Structures([torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in prots],
+                    [torch.from_numpy(p["z_full"])[1:-1] for p in prots], "cpu")
+    members = [0, 1, 2, 3, 4, 5, 6, 3, 1]
+    job = Job(st, members, "cpu")
+    for k in (2, 3):
+        parts = job.parts(k)
+        assert parts is job.parts(k) and len(parts) == k                       # built once
+        seen = torch.zeros(job.n_nodes, dtype=torch.int32)
+        start = 0
+        for p, (sub, idx) in enumerate(parts):
+            mine = members[p::k]
+            assert sub.sample_struct == mine and sub.n_nodes == int(idx.numel()) == sum(lens[m] for m in mine)
+            seen[idx] += 1
+            alone = Job(st, mine, "cpu")
+            assert torch.equal(sub.node_info, alone.node_info) and torch.equal(sub.tile_list, alone.tile_list)
+            # the node indices are those of the part's samples in the parent, in order
+            want = np.concatenate([np.arange(job.sample_off[m], job.sample_off[m + 1]) for m in range(p, len(members), k)])
+            assert idx.tolist() == want.tolist()
+            # source structure node of every part node = the parent's at the same place
+            assert torch.equal(sub.node_info[:, 0], job.node_info[idx][:, 0])
+            assert sub.hE.data_ptr() == job.hE[start:start + sub.n_nodes].data_ptr() and sub.hE.is_contiguous()
+            start += sub.n_nodes
+        assert start == job.n_nodes and bool((seen == 1).all())
