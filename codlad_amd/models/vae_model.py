@@ -111,10 +111,30 @@ class e3nnPrior(nn.Module):
         return self.engine().forward(cg_z, cg_xyz, cg_nbr_list)
 
 
+_LENS_CACHE = {}
+
+
+def batch_lengths(num_CGs):
+    """`num_CGs.tolist()`, read from the device ONCE per tensor: the reference's helpers need the lengths on the host
+    (gcn_nn.py:35-43, 45-52) and ask the device for them at every call - two synchronisations per encoder pass, 2 of the 5 ms
+    of a 40-frame batch.  The copy is kept per (storage, version), so a batch that is encoded, sampled and decoded pays
+    one read."""
+    if not num_CGs.is_cuda:
+        return num_CGs.tolist()
+    key = (num_CGs.data_ptr(), num_CGs._version, int(num_CGs.numel()), str(num_CGs.device))
+    lens = _LENS_CACHE.get(key)
+    if lens is None:
+        if len(_LENS_CACHE) >= 256:
+            _LENS_CACHE.clear()
+        lens = _LENS_CACHE[key] = num_CGs.tolist()
+    return lens
+
+
 def reshape_and_create_mask(h, num_CGs):
     """reference gcn_nn.py:35-43"""
-    reshaped = torch.nn.utils.rnn.pad_sequence(torch.split(h, num_CGs.tolist(), dim=0), batch_first=True)
-    mask = torch.arange(int(num_CGs.max()), device=h.device)[None, :] < num_CGs[:, None]
+    lens = batch_lengths(num_CGs)
+    reshaped = torch.nn.utils.rnn.pad_sequence(torch.split(h, lens, dim=0), batch_first=True)
+    mask = torch.arange(max(lens), device=h.device)[None, :] < num_CGs[:, None]
     return reshaped, mask
 
 
@@ -267,7 +287,7 @@ class VAE(nn.Module):
 
     @staticmethod
     def _flatten(latent, num_CGs):
-        lens = num_CGs.tolist()
+        lens = batch_lengths(num_CGs)
         if len(set(lens)) == 1 and latent.shape[1] == lens[0]:
             return latent.reshape(-1, latent.shape[-1])
         return torch.cat([latent[b, :n] for b, n in enumerate(lens)], dim=0)   # gcn_nn.restore_shape
