@@ -117,17 +117,18 @@ _LENS_CACHE = {}
 def batch_lengths(num_CGs):
     """`num_CGs.tolist()`, read from the device ONCE per tensor: the reference's helpers need the lengths on the host
     (gcn_nn.py:35-43, 45-52) and ask the device for them at every call - two synchronisations per encoder pass, 2 of the 5 ms
-    of a 40-frame batch.  The copy is kept per (storage, version), so a batch that is encoded, sampled and decoded pays
-    one read."""
+    of a 40-frame batch.  The copy is kept per (storage, version) together with the tensor itself, so a batch that is
+    encoded, sampled and decoded pays one read."""
     if not num_CGs.is_cuda:
         return num_CGs.tolist()
     key = (num_CGs.data_ptr(), num_CGs._version, int(num_CGs.numel()), str(num_CGs.device))
-    lens = _LENS_CACHE.get(key)
-    if lens is None:
-        if len(_LENS_CACHE) >= 256:
+    hit = _LENS_CACHE.get(key)
+    if hit is None:
+        if len(_LENS_CACHE) >= 16:
             _LENS_CACHE.clear()
-        lens = _LENS_CACHE[key] = num_CGs.tolist()
-    return lens
+        # the entry keeps the tensor alive: its address cannot be handed to another batch's lengths while the key exists
+        hit = _LENS_CACHE[key] = (num_CGs.tolist(), num_CGs)
+    return hit[0]
 
 
 def reshape_and_create_mask(h, num_CGs):

@@ -394,3 +394,20 @@ def test_genzprot_and_recon_models_run_end_to_end():
     assert rel_err(lat, lat_ref) < 1e-5
     _ic, ic_recon = n6.latent_decode(lat, mask, dbatch)
     assert ic_recon.shape == (92, 13, 3) and bool(torch.isfinite(ic_recon).all())
+
+
+@pytest.mark.gpu
+def test_batch_lengths_are_read_once_and_never_stale():
+    """models.vae_model.batch_lengths keeps a host copy of a batch's `num_CGs` per tensor.  A freed tensor's address is
+    handed out again by the caching allocator - the next batch's lengths land where the last batch's were - so an entry
+    keeps its tensor alive (the first version of the cache did not, and test.py decoded the L = 92 batch with L = 87's
+    lengths)."""
+    from codlad_amd.models.vae_model import batch_lengths
+    for L in (87, 92, 46, 129, 87):
+        t = torch.tensor([L, L], dtype=torch.int64, device=DEV)
+        assert batch_lengths(t) == [L, L]
+        assert batch_lengths(t) == [L, L]
+        t[1] = 5                                    # in-place change: another version, another entry
+        assert batch_lengths(t) == [L, 5]
+        del t
+    assert batch_lengths(torch.tensor([3, 4])) == [3, 4]          # host tensors are read directly

@@ -66,7 +66,36 @@ __device__ inline float rnd(unsigned &s) {
     return ((s >> 8) & 0xffff) * (1.0f / 32768.0f) - 1.0f;
 }
 
-template <int SHAPE>
+// energy shares of the production contraction (SHAPE 32 only): MODE 1 = the matrix instructions and their LDS fragment reads alone
+// (operand fragments split once, outside the loop), MODE 2 = the GELU + split vector stream alone (fragments folded into a sum)
+template <int MODE>
+DEV void part32(Tile &acc, const Tile &in, const u32x4 *wl, int lane, const GeluK &gk, SplitFrag (&pre)[8]) {
+    const u32x4 *w = wl + lane;
+    if (MODE == 1) {
+        u32x4 ring[3][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { ring[g][0] = w[(g * 2 + 0) * 64]; ring[g][1] = w[(g * 2 + 1) * 64]; }
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            if (g + 2 < 32) { ring[(g + 2) % 3][0] = w[((g + 2) * 2 + 0) * 64]; ring[(g + 2) % 3][1] = w[((g + 2) * 2 + 1) * 64]; }
+            mfma_f16<3>(acc.b[g & 3], as_f16x8(ring[g % 3][0]), as_f16x8(ring[g % 3][1]), pre[g >> 2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            SplitFrag x;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) split_pair<true>(x, in, ks, p, gk);
+            const u32x4 a = __builtin_bit_cast(u32x4, x.hi), b = __builtin_bit_cast(u32x4, x.lo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc.b[ks & 3][4 * (ks >> 2) + i] += __builtin_bit_cast(float, (a[i] & 0x007fffffu) | 0x3f800000u) * 1e-3f
+                                                                          + __builtin_bit_cast(float, (b[i] & 0x007fffffu) | 0x3f800000u) * 1e-3f;
+        }
+    }
+}
+
+template <int SHAPE, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void k(int iters, const u32x4 *wg, float *out, long long *cyc) {
     extern __shared__ __align__(16) u32x4 wl[];
     for (int i = threadIdx.x; i < 4096; i += 512) wl[i] = wg[i];
@@ -80,8 +109,12 @@ __global__ __launch_bounds__(512, 2) void k(int iters, const u32x4 *wg, float *o
         Tile in, acc;
         for (int b = 0; b < 4; ++b)
             for (int q = 0; q < 16; ++q) { in.b[b][q] = 1.5f * rnd(seed); acc.b[b][q] = 0.f; }
+        SplitFrag pre[8];
+        for (int ks = 0; ks < 8; ++ks)
+            for (int p = 0; p < 4; ++p) split_pair<true>(pre[ks], in, ks, p, gk);
         for (int it = 0; it < iters; ++it) {
-            gemm128_h_lds<3, true>(acc, in, wl, lane, gk);
+            if (MODE == 0) gemm128_h_lds<3, true>(acc, in, wl, lane, gk);
+            else part32<MODE>(acc, in, wl, lane, gk, pre);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -112,15 +145,15 @@ __global__ __launch_bounds__(512, 2) void k(int iters, const u32x4 *wg, float *o
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int SHAPE>
+template <int SHAPE, int MODE = 0>
 void run(const u32x4 *wg, float *out, long long *cyc) {
     const int iters = 2000;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k<SHAPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    k<SHAPE><<<256, 512, 65536>>>(200, wg, out, cyc);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k<SHAPE, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    k<SHAPE, MODE><<<256, 512, 65536>>>(200, wg, out, cyc);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
-    k<SHAPE><<<256, 512, 65536>>>(iters, wg, out, cyc);
+    k<SHAPE, MODE><<<256, 512, 65536>>>(iters, wg, out, cyc);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -132,8 +165,8 @@ void run(const u32x4 *wg, float *out, long long *cyc) {
     c /= 256.0 * iters;
     float probe;
     (void)hipMemcpy(&probe, out, 4, hipMemcpyDeviceToHost);
-    printf("%2dx%2d  2 waves/SIMD: %7.0f shader cycles per contraction per wave, %6.3f us per contraction per wave, clock %.2f GHz  (check %g)\n",
-           SHAPE, SHAPE, c, ms * 1e3 / iters, c / (ms * 1e3 / iters) / 1e3, probe);
+    printf("%2dx%2d %s 2 waves/SIMD: %7.0f shader cycles per contraction per wave, %6.3f us per contraction per wave, clock %.2f GHz  (check %g)\n",
+           SHAPE, SHAPE, MODE == 0 ? "           " : (MODE == 1 ? "matrix only" : "vector only"), c, ms * 1e3 / iters, c / (ms * 1e3 / iters) / 1e3, probe);
 }
 
 int main() {
@@ -152,6 +185,8 @@ int main() {
     for (int rep = 0; rep < 3; ++rep) {
         run<32>(wg, out, cyc);
         run<16>(wg, out, cyc);
+        run<32, 1>(wg, out, cyc);
+        run<32, 2>(wg, out, cyc);
     }
     return 0;
 }
