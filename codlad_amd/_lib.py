@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 12   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
+ABI_VERSION = 13   # CODLAD_ABI_VERSION of include/codlad_hip.h this binding was written against
 # CODLAD_HIP_LIB: an alternative build of the same ABI (A/B measurements, tools/ablate_edge.py)
 LIB_PATH = os.environ.get("CODLAD_HIP_LIB") or os.path.join(_HERE, "libcodlad_hip.so")
 
@@ -152,7 +152,7 @@ def lib():
     return _lib
 
 
-OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT, OPT_TP_CONV_VARIANT, OPT_EDGE_UPD_VARIANT, OPT_EDGE_CUS = 0, 1, 3, 4, 5, 6   # CODLAD_OPT_* of include/codlad_hip.h
+OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT, OPT_TP_CONV_VARIANT, OPT_EDGE_UPD_VARIANT, OPT_EDGE_CUS, OPT_EDGE_WIDE_MAX_TILES = 0, 1, 3, 4, 5, 6, 7   # CODLAD_OPT_* of include/codlad_hip.h
 
 
 def set_option(option, value):

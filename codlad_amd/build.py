@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
 SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_upd1_kernel.hip", "edge_tile_kernels.hip",
+           "edge_wide_kernels.hip",
            "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
            "ic_decoder_kernels.hip", "encoder_kernels.hip", "encoder_mfma_kernel.hip", "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
@@ -26,6 +27,7 @@ EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip":
                # each (3 instructions for min(|x|, c)); nothing on this path produces or tests NaN
                "denoiser_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_tile_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               "edge_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_msg_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                "edge_upd_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
                # one wave per SIMD: with a 512-register budget hipcc selects the AGPR form of every MFMA (accumulators in

@@ -494,6 +494,8 @@ hipError_t codlad_take_attr_error() {
 
 // edge_tile_kernels.hip, edge_msg_kernel.hip, edge_upd_kernel.hip
 void launch_edge_tile(int terms, bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st);
+void launch_edge_wide(int terms, bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st);   // edge_wide_kernels.hip
+int edge_wide_max_tiles();
 void launch_edge_msg(int terms, const EdgeArgs &ea, hipStream_t st);
 void launch_edge_upd(int terms, const EdgeArgs &ea, hipStream_t st);
 void launch_edge_upd1(int terms, const EdgeArgs &ea, hipStream_t st);     // edge_upd1_kernel.hip: one wave per SIMD
@@ -501,6 +503,7 @@ int edge_upd_variant();
 
 template <int TERMS>
 static void launch_edge_h(bool update, const EdgeArgs &ea, const int2 *tile_list, int n_tiles, hipStream_t st) {
+    if (tile_list && n_tiles <= edge_wide_max_tiles()) return launch_edge_wide(TERMS, update, ea, tile_list, n_tiles, st);
     if (tile_list) return launch_edge_tile(TERMS, update, ea, tile_list, n_tiles, st);
     if (update) {
         // upd1_kernel_h gives every node two tiles: worth it while (nearly) every node has two (n_tiles counts the
@@ -612,6 +615,9 @@ static int nodeq_max_tiles() { return option_or(CODLAD_OPT_NODEQ_MAX_TILES, "COD
 int dec_edge_variant() { return option_or(CODLAD_OPT_DEC_EDGE_VARIANT, "CODLAD_DEC_EDGE_VARIANT", 0); }
 int tp_conv_variant() { return option_or(CODLAD_OPT_TP_CONV_VARIANT, "CODLAD_TP_CONV_VARIANT", 0); }
 int edge_upd_variant() { return option_or(CODLAD_OPT_EDGE_UPD_VARIANT, "CODLAD_EDGE_UPD_VARIANT", 0); }
+// measured (tools/small_job_latency.py --sweep, k x 87 residues): the four-wave tile kernels win or tie up to ~5 600 tiles
+// (2 800 nodes; 87 nodes 375 -> 254 us per step, 1 914 nodes 764 -> 594), beyond that the per-node kernels' reuse wins
+int edge_wide_max_tiles() { return option_or(CODLAD_OPT_EDGE_WIDE_MAX_TILES, "CODLAD_EDGE_WIDE_MAX_TILES", 22 * num_cu()); }
 int edge_cus() {
     const int v = option_or(CODLAD_OPT_EDGE_CUS, "CODLAD_EDGE_CUS", 0);
     return v > 0 && v < num_cu() ? v : num_cu();
@@ -671,7 +677,8 @@ static void enqueue_forward(const codlad_denoiser_weights *w, const int32_t *nod
     const bool split = w->precision != 0;
     // small jobs: edge kernels per 32-edge tile, message sums per half (S[2][n_nodes][128])
     // (while every wave of the persistent grid gets at most one tile: beyond that the per-node order is as good)
-    const bool tilewise = split && ws->tile_list && ws->n_tiles > 0 && ws->n_tiles <= 8 * num_cu() &&
+    const bool tilewise = split && ws->tile_list && ws->n_tiles > 0 &&
+                          (ws->n_tiles <= 8 * num_cu() || ws->n_tiles <= edge_wide_max_tiles()) &&
                           n_nodes <= edge_tile_max_nodes();
     const int2 *tile_list = tilewise ? reinterpret_cast<const int2 *>(ws->tile_list) : nullptr;
 

@@ -37,6 +37,12 @@ struct EdgeArgs {
     float res_scale, ln_eps;
 };
 
+// small jobs: the work dealt out per non-empty 32-edge tile {node, half} (edge_tile_kernels.hip, edge_wide_kernels.hip)
+struct EdgeTileArgs : EdgeArgs {
+    const int2 *tile_list;
+    int n_tiles;
+};
+
 #define LDS_BLOCK_U4 4096   // one 64 KB packed block in 16-byte words
 
 // XCD-aware node placement.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8

@@ -9,10 +9,6 @@
 // struct: the per-node kernels above sit exactly at the 256-register limit and any change to their signature
 // or body shape makes hipcc spill in their inner loops (-9 % measured).
 // ---------------------------------------------------------------------------------------------
-struct EdgeTileArgs : EdgeArgs {
-    const int2 *tile_list;
-    int n_tiles;
-};
 
 // Edge update, per tile:
 //   h_E[n,j] <- mod3(LN(h_E[n,j] + W13 GELU(W12 GELU(P_i + Q_j + W11e h_E[n,j]) + b12) + b13))

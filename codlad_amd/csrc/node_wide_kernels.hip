@@ -19,11 +19,11 @@
 // node_kernel_h (tests/test_hip_parity.py).  Critical path: W3 | LN | 2 x W_in | 4 x W_out | LN | 2 projections = 9
 // short contractions of 24 MFMAs instead of 13 of 96.
 #include "node_args.h"
+#include "wide_common.h"
 
 namespace {
 
 constexpr int WIDE_WAVES = 8;
-constexpr int FRAG_U4 = 1024;                        // one tile as fragments: [8 k-steps][hi, lo][64 lanes] x 16 B
 // LDS map in 16-byte words
 constexpr int L_FRAG_A = 0;                          // input fragments of the current phase (S, v, projection input)
 constexpr int L_FRAG_B = L_FRAG_A + FRAG_U4;         // projection input h_V + h_Venc
@@ -34,87 +34,19 @@ constexpr int L_VEC = L_MOD + 128;                   // b3, b_in[4], b_out, proj
 constexpr int L_END = L_VEC + 10 * 32;
 constexpr int WIDE_LDS_BYTES = L_END * 16;
 
-struct BlockQuarter {                                // the weight fragments of one output block of one 128x128 block
-    u32x4 w[8][2];
-    DEV void start(const void *Wpacked, int bo, int lane) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wpacked), 0, 65536, 0x00020000);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            w[ks][0] = weight_frag_load(rsrc, lane, (ks * 4 + bo) * 2 + 0);
-            w[ks][1] = weight_frag_load(rsrc, lane, (ks * 4 + bo) * 2 + 1);
-        }
-    }
-    // acc += W[32 bo .. 32 bo + 31][:] @ tile, the tile read as fragments from LDS
-    template <int TERMS>
-    DEV void run(f32x16 &acc, const u32x4 *frag, int lane) const {
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            SplitFrag x;
-            x.hi = as_f16x8(frag[(ks * 2 + 0) * 64 + lane]);
-            x.lo = as_f16x8(frag[(ks * 2 + 1) * 64 + lane]);
-            mfma_f16<TERMS>(acc, as_f16x8(w[ks][0]), as_f16x8(w[ks][1]), x);
-        }
-    }
-};
-
-// The 16 registers of output block `bo` ARE the elements of the fragments of k-steps 2 bo and 2 bo + 1 (register
-// 8 s + j = element j of k-step 2 bo + s): activate (optionally), split, write both fragments.
-template <bool GELU>
-DEV void publish_quarter(u32x4 *frag, f32x16 q, int bo, int lane, const GeluK &gk) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        SplitFrag f;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            f32x2 x = {q[8 * s + 2 * p], q[8 * s + 2 * p + 1]};
-            if (GELU) {
-                f32x2 t[1] = {x};
-                gelu_pairs<1>(t, gk);
-                x = t[0];
-            }
-            const f16x2 hh = __builtin_convertvector(x, f16x2);
-            const f16x2 ll = split_lo_pair(hh, x);
-            f.hi[2 * p] = hh.x; f.hi[2 * p + 1] = hh.y;
-            f.lo[2 * p] = ll.x; f.lo[2 * p + 1] = ll.y;
-        }
-        frag[((2 * bo + s) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, f.hi);
-        frag[((2 * bo + s) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, f.lo);
-    }
-}
-
-DEV void quarter_load(f32x16 &a, const float *row, int bo, int h) {     // this wave's block of a 128-float vector
-    const float4 *p = reinterpret_cast<const float4 *>(row);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = p[8 * bo + 2 * q + h];
-        a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-    }
-}
-DEV void quarter_store(const f32x16 &a, float *row, int bo, int h) {
-    float4 *p = reinterpret_cast<float4 *>(row);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[8 * bo + 2 * q + h] = make_float4(a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-}
-DEV f32x16 quarter_of(const Tile &t, int bo) {       // bo is wave-uniform
-    return bo == 0 ? t.b[0] : (bo == 1 ? t.b[1] : (bo == 2 ? t.b[2] : t.b[3]));
-}
-DEV void xch_write(float4 *buf, const f32x16 &a, int bo, int h, int c) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) buf[(8 * bo + 2 * q + h) * 32 + c] = make_float4(a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-}
-DEV void xch_read(Tile &t, const float4 *buf, int h, int c) {
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = buf[(8 * bo + 2 * q + h) * 32 + c];
-            t.b[bo][4 * q + 0] = v.x; t.b[bo][4 * q + 1] = v.y; t.b[bo][4 * q + 2] = v.z; t.b[bo][4 * q + 3] = v.w;
-        }
-}
+#ifdef NW_STAMP      // diagnostic build (tools/edge_variants.py): phase stamps of workgroup 0's first wave, left in h_V[0][0..]
+#define NW_MARK(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NW_MARK(i) do {} while (0)
+#endif
 
 template <bool MODE_UPD, int TERMS>
 __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
+#ifdef NW_STAMP
+    unsigned long long stamp[16] = {};
+#endif
+    NW_MARK(0);
     u32x4 *fragA = wl + L_FRAG_A, *fragB = wl + L_FRAG_B;
     float4 *xch = reinterpret_cast<float4 *>(wl + L_XCH);
     const float *modAB = reinterpret_cast<const float *>(wl + L_MOD);
@@ -152,6 +84,11 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
     // the tile's own rows (lead waves), requested before anything is waited for
     Tile v;
     f32x16 sq;
+#ifdef NW_STAMP
+    NW_MARK(10);
+    { int z = info.z; asm volatile("" : "+v"(z)); }
+    NW_MARK(11);
+#endif
     if (MODE_UPD && lead) {
         quarter_load(sq, a.S + (size_t)nc * HD, bo, h);
         if (a.s_partials) {       // tile kernels: one partial per half and lane half, planes half + 2 h; same order as msg_kernel_h
@@ -192,9 +129,15 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
         // ---- phase A: t = W3 @ (S / 64) + K b3 / 64, v = LN1(h_V + 64 t / 30) ------------------------------
         if (lead) {
             sq *= a.s_scale;
+#ifdef NW_STAMP
+            asm volatile("" : "+v"(sq));
+            NW_MARK(12);
+#endif
             publish_quarter<false>(fragA, sq, bo, lane, plain);
         }
+        NW_MARK(13);
         __syncthreads();                                     // S fragments, staged vectors, modAB
+        NW_MARK(1);
         if (lead) {
             f32x16 q;
             quarter_load(q, lv, bo, h);
@@ -203,6 +146,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
             xch_write(xch, q, bo, h, c);
         }
         __syncthreads();
+        NW_MARK(2);
         if (lead) {
             Tile t;
             xch_read(t, xch, h, c);
@@ -215,6 +159,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
             w0.start(a.blk_h[5], bo, lane);                  // W_in 2 (after the LayerNorm: registers)
         }
         __syncthreads();
+        NW_MARK(3);
         // ---- phase B1: hidden chunk = GELU(W_in[chunk] @ v + b_in[chunk]); chunks g and g + 2 ----------------
         {
             f32x16 q;
@@ -238,6 +183,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
             publish_quarter<true>(wl + L_HID + (2 + g) * FRAG_U4, q, bo, lane, a.gelu_ffn);
         }
         __syncthreads();
+        NW_MARK(4);
         // ---- phase B2: t = b_out + sum_ch W_out[ch] @ hidden[ch] (one accumulator, chunk after chunk) -----
         if (lead) {
             f32x16 q;
@@ -252,6 +198,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
             xch_write(xch, q, bo, h, c);
         }
         __syncthreads();
+        NW_MARK(5);
         if (lead) {
             Tile t;
             xch_read(t, xch, h, c);
@@ -263,6 +210,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
     } else {
         __syncthreads();                                     // staged vectors
     }
+    NW_MARK(6);
     // ---- new h_V: store, publish the projection inputs ----------------------------------------------------
     bool any_sum = false;
     for (int p = 0; p < a.n_proj; ++p) any_sum |= (a.proj_flags[p] & 1) != 0;
@@ -312,6 +260,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
         }
     }
     __syncthreads();
+    NW_MARK(7);
     // ---- phase C: projections g and g + 2 on the waves (g, bo) ----------------------------------------------
     auto project = [&](int p, const BlockQuarter &wp) {
         const int fl = a.proj_flags[p];
@@ -328,6 +277,17 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void node_kernel_w(NodeArgs a) 
     // buffers: input kernel w0 / w1; update kernel: lead w1 (projection 0) / w0 (projection 2), others w0 / w1
     if (g < a.n_proj) project(g, (MODE_UPD && lead) ? w1 : w0);
     if (g + 2 < a.n_proj) project(g + 2, (MODE_UPD && lead) ? w0 : w1);
+#ifdef NW_STAMP
+    NW_MARK(8);
+    __builtin_amdgcn_s_waitcnt(0);
+    NW_MARK(9);
+    if (MODE_UPD && blockIdx.x == 0 && tid == 0)
+    {
+        for (int i = 0; i < 9; ++i) a.hV[i] = (float)(stamp[i + 1] - stamp[i]);
+        a.hV[9] = (float)(stamp[10] - stamp[0]); a.hV[10] = (float)(stamp[11] - stamp[10]);
+        a.hV[11] = (float)(stamp[12] - stamp[11]); a.hV[12] = (float)(stamp[13] - stamp[12]); a.hV[13] = (float)(stamp[1] - stamp[13]);
+    }
+#endif
 }
 
 template <int TERMS>

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CODLAD_ABI_VERSION 12
+#define CODLAD_ABI_VERSION 13
 #define CODLAD_H 128          /* hidden width of the denoiser                          */
 #define CODLAD_KNN 64         /* k_neighbors (reference models/latent_model.py:86)      */
 #define CODLAD_MODS_PER_STEP 6016 /* 3*9*128 (enc) + 3*6*128 (dec) + 2*128 (final)      */
@@ -393,13 +393,16 @@ int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t 
  *   CODLAD_OPT_EDGE_UPD_VARIANT  edge update of large jobs: 0 = two waves per SIMD (upd_kernel_h); 1 = one wave per SIMD with
  *                                the next tile prefetched (upd1_kernel_h) where nearly every node has two 32-edge tiles;
  *                                2 = that kernel for every job.  Bit-identical; same speed on MI355X (profiles/r04_upd1_*)
- *   CODLAD_OPT_EDGE_CUS          persistent workgroups of the per-node edge kernels (0 / >= CU count: one per CU) */
+ *   CODLAD_OPT_EDGE_CUS          persistent workgroups of the per-node edge kernels (0 / >= CU count: one per CU)
+ *   CODLAD_OPT_EDGE_WIDE_MAX_TILES  tile-wise jobs of up to this many 32-edge tiles give a tile to FOUR waves (one output
+ *                                block each, weight quarters in registers: edge_wide_kernels.hip) instead of one; same bits */
 #define CODLAD_OPT_NODEQ_MAX_TILES 0
 #define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
 #define CODLAD_OPT_DEC_EDGE_VARIANT 3
 #define CODLAD_OPT_TP_CONV_VARIANT 4
 #define CODLAD_OPT_EDGE_UPD_VARIANT 5
 #define CODLAD_OPT_EDGE_CUS 6
+#define CODLAD_OPT_EDGE_WIDE_MAX_TILES 7
 #define CODLAD_N_OPTIONS 8
 int codlad_set_option(int option, int value);
 

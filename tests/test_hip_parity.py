@@ -17,6 +17,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+EDGE_WIDE_DEFAULT = 22 * 256      # CODLAD_OPT_EDGE_WIDE_MAX_TILES as shipped (22 x the CU count)
 EDGE_UPD_DEFAULT = 0      # the library's default CODLAD_OPT_EDGE_UPD_VARIANT
 
 
@@ -630,6 +631,7 @@ def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
     for max_nodes, wide_tiles in ((0, 256), (1 << 20, 256), (1 << 20, 0)):
         _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, max_nodes)
         _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, wide_tiles)
+        _lib.set_option(_lib.OPT_EDGE_WIDE_MAX_TILES, 0)      # the one-wave tile kernels (the four-wave ones: next test)
         try:
             d = Denoiser(sd, DEV, precision="f16x3")
             job = d.make_job(d.prepare_structures(xyz, zz), list(range(len(lens))))
@@ -641,6 +643,7 @@ def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
         finally:
             _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, 1 << 30)
             _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, 256)
+            _lib.set_option(_lib.OPT_EDGE_WIDE_MAX_TILES, EDGE_WIDE_DEFAULT)
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
     off = np.concatenate([[0], np.cumsum(lens)])
@@ -650,6 +653,42 @@ def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
         a, b = int(off[k]), int(off[k + 1])
         ref = oden.forward(sd, x[a:b].cpu()[None], torch.tensor([600]), cg_xyz, cg_z, m)
         assert rel_err(outs[1][0][a:b], ref[0]) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x4"])
+def test_small_job_wide_edge_kernels_are_bit_identical(sd, precision):
+    """msg_wide_kernel / upd_wide_kernel (edge_wide_kernels.hip: four waves per 32-edge tile, one output block each, weight
+    quarters in registers, the LayerNorm's moments streamed from LDS in the one-wave order) against the one-wave tile
+    kernels and the per-node kernels: bit-identical, with and without the hoisted layer-0 terms, on lengths that give
+    empty, partial and full second halves; also with fewer workgroups than tiles (a workgroup walks several tiles)."""
+    lens = [5, 31, 32, 33, 47, 64, 87, 120]
+    prots = [synth.make_protein(L, 500 + i, n_frames=1) for i, L in enumerate(lens)]
+    xyz = [torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in prots]
+    zz = [torch.from_numpy(p["z_full"])[1:-1] for p in prots]
+    members = list(range(len(lens))) + [7, 6, 0] + [7] * 2
+    n = sum(lens[m] for m in members)
+    x = synth.gaussian((n, 3), 37).to(DEV)
+    T = 3
+    eps = synth.gaussian((T, n, 3), 38).to(DEV)
+    outs = []
+    try:
+        # per-node kernels | one-wave tile kernels | wide kernels
+        for max_nodes, wide in ((0, 0), (1 << 20, 0), (1 << 20, 1 << 20)):
+            _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, max_nodes)
+            _lib.set_option(_lib.OPT_EDGE_WIDE_MAX_TILES, wide)
+            d = Denoiser(sd, DEV, precision=precision)
+            for hoist in (True, False):
+                job = d.make_job(d.prepare_structures(xyz, zz, hoist_layer0=hoist), members)
+                if wide:
+                    assert 2 * 256 < job.ws.n_tiles <= 8 * 256      # more tiles than the wide kernels' grid: workgroups loop
+                outs.append((d.forward(job, x, 600), d.sample(job, x, eps, tables(T))))
+    finally:
+        _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, 1 << 30)
+        _lib.set_option(_lib.OPT_EDGE_WIDE_MAX_TILES, EDGE_WIDE_DEFAULT)
+    for k in range(2):
+        assert bool(torch.isfinite(outs[k][0]).all())
+        for v in (1, 2):
+            assert torch.equal(outs[k][0], outs[2 * v + k][0]) and torch.equal(outs[k][1], outs[2 * v + k][1]), (precision, k, v)
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f16x4"])

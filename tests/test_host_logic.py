@@ -315,6 +315,13 @@ def test_hot_edge_kernels_keep_their_register_budget():
                  "_Z13upd1_kernel_hILb0ELi4EEv8EdgeArgs", "_Z13upd1_kernel_hILb1ELi4EEv8EdgeArgs"):
         r = table[name]
         assert r["Occupancy"] == 1 and r["ScratchSize"] == 0, (name, r)
+    # small jobs: the four-wave message kernels keep their two weight quarters in registers without scratch; the edge
+    # update (three quarters in flight) may park a few registers of W11e's
+    for name, r in table.items():
+        if "msg_wide_kernel" in name:
+            assert r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (name, r)
+        if "upd_wide_kernel" in name:
+            assert r["ScratchSize"] <= 64 and r["Occupancy"] == 2, (name, r)
 
 
 @pytest.mark.parametrize("name", list(cases.INFO_CASES))

@@ -17,6 +17,8 @@ from codlad_amd.engine import Denoiser                                          
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--sweep", action="store_true", help="k copies of one 87-residue protein, k = 1 .. 24, instead of the four cases")
+ap.add_argument("--ks", default="", help="--sweep: comma-separated copy counts")
 args = ap.parse_args()
 
 torch.set_grad_enabled(False)
@@ -27,6 +29,8 @@ shard = parallel.shard_units([parallel.unit_cost(L) for L in cfg3], 8)[0]
 CASES = [("1 protein, L=87", [87]), ("1 protein, L=300", [300]),
          ("cfg3 shard of one GPU (1/8, LPT): %d proteins" % len(shard), [cfg3[u] for u in shard]),
          ("cfg3, all 64 proteins", cfg3)]
+if args.sweep:
+    CASES = [("%d x L=87" % k, [87] * k) for k in ([int(v) for v in args.ks.split(",")] if args.ks else (1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24))]
 for k, (label, lens) in enumerate(CASES):
     if args.only >= 0 and k != args.only:
         continue
