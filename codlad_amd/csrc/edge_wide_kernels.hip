@@ -108,46 +108,6 @@ DEV void quarter_presplit(f32x16 &t) {
     }
 }
 
-// tile_layernorm_affine on a tile that lies in LDS as [32 chunks][32 columns] float4 (xch_write): the column's values of
-// this lane half are streamed through the two moment sums in the order the one-wave kernel adds its registers (block
-// after block, pairs of registers on two interleaved partial sums).  `own` = this wave's block bo of the same tile (the
-// registers it wrote to the buffer), normalised and modulated in place.
-DEV void xch_layernorm_affine(f32x16 &own, const float4 *buf, float eps, const float *A, const float *B, int bo, int h, int c) {
-    f32x2 s2 = {0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = buf[(8 * b + 2 * q + h) * 32 + c];
-            s2 += f32x2{v.x, v.y};
-            s2 += f32x2{v.z, v.w};
-        }
-    const float mean = column_sum128(s2.x + s2.y) * (1.0f / 128.0f);
-    const f32x2 m2 = {mean, mean};
-    f32x2 v2 = {0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = buf[(8 * b + 2 * q + h) * 32 + c];
-            const f32x2 d0 = f32x2{v.x, v.y} - m2;
-            v2 = d0 * d0 + v2;
-            const f32x2 d1 = f32x2{v.z, v.w} - m2;
-            v2 = d1 * d1 + v2;
-        }
-    const float rstd = 1.0f / sqrtf(column_sum128(v2.x + v2.y) * (1.0f / 128.0f) + eps);
-    const f32x2 r2 = {rstd, rstd};
-    const float4 *pa = reinterpret_cast<const float4 *>(A);
-    const float4 *pb = reinterpret_cast<const float4 *>(B);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int o = 8 * bo + 2 * q + h;
-        const float4 ka = pa[o], kb = pb[o];
-        tile_set_pair(own, 4 * q, (tile_pair(own, 4 * q) - m2) * (r2 * f32x2{ka.x, ka.y}) + f32x2{kb.x, kb.y});
-        tile_set_pair(own, 4 * q + 2, (tile_pair(own, 4 * q + 2) - m2) * (r2 * f32x2{ka.z, ka.w}) + f32x2{kb.z, kb.w});
-    }
-}
-
 // Edge update, per tile:
 //   h_E[n,j] <- mod3(LN(h_E[n,j] + W13 GELU(W12 GELU(P_i + Q_j + W11e h_E[n,j]) + b12) + b13))
 // HOISTED: encoder layer 0 with a.E1 given - layer 1's edge contraction comes precomputed.
@@ -157,19 +117,33 @@ DEV void xch_layernorm_affine(f32x16 &own, const float4 *buf, float eps, const f
 template <bool HOISTED, int TERMS>
 __global__ __launch_bounds__(EW_WAVES * 64, 2) void upd_wide_kernel(EdgeTileArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
+    // every argument in one batch, pinned (wide_common.h)
+    const int2 *tile_list = a.tile_list;
+    const int4 *node_info = a.node_info;
+    const int32_t *E_idx = a.E_idx;
+    const float *hE_in = a.hE_in, *E1 = a.E1, *P = a.P, *Q = a.Q;
+    float *hE_out = a.hE_out;
+    const void *W1h = a.W1h, *W2h = a.W2h, *W3h = a.W3h;
+    int n_tiles = a.n_tiles, in_by_src = a.in_by_src;
+    float res_scale = a.res_scale, ln_eps = a.ln_eps;
+    GeluK gelu_a = a.gelu_a, gelu_b = a.gelu_b;
+    PIN_PTR(tile_list); PIN_PTR(node_info); PIN_PTR(E_idx); PIN_PTR(hE_in); PIN_PTR(E1); PIN_PTR(P); PIN_PTR(Q); PIN_PTR(hE_out);
+    PIN_PTR(W1h); PIN_PTR(W2h); PIN_PTR(W3h); PIN1(n_tiles); PIN1(in_by_src); PIN1(res_scale); PIN1(ln_eps);
+    pin_gelu(gelu_a); pin_gelu(gelu_b);
+    asm volatile("" :: "s"(a.b2), "s"(a.b3), "s"(a.mods3));
     u32x4 *fragX = wl + EW_FRAG_X, *fragA = wl + EW_FRAG_A, *fragB = wl + EW_FRAG_B;
     float4 *xch = reinterpret_cast<float4 *>(wl + EW_XCH);
     const float *c_b2 = reinterpret_cast<const float *>(wl + EW_VEC), *c_b3 = c_b2 + HD;
     const float *c_modA = c_b2 + 2 * HD, *c_modB = c_b2 + 3 * HD;
     const int tid = threadIdx.x, lane = tid & 63, bo = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
+    // W12's quarter stays in registers for all of the workgroup's tiles; W11e's and W13's are requested per tile (three
+    // resident quarters leave too few registers for a tile at two waves per SIMD: the compiler then parks arriving
+    // fragments in scratch, and every scratch access waits for ALL outstanding loads)
     BlockQuarter w1, w2, w3;
-    if (!HOISTED) w1.start(a.W1h, bo, lane);
-    w2.start(a.W2h, bo, lane);
-    // three resident quarters (192 registers) leave too few for a tile at two waves per SIMD: with layer 1 in the kernel
-    // W13's quarter is requested per tile, after layer 1 (its L2 latency passes under the publish and layer 2)
-    if (HOISTED) w3.start(a.W3h, bo, lane);
-    {   // per-launch vectors -> LDS (the folded modulation exactly as the tile kernels compute it)
+    w2.start(W2h, bo, lane);
+    {   // per-launch vectors -> LDS (the folded modulation exactly as the tile kernels compute it); first read after the
+        // first barrier of the tile loop
         const int i = tid & 31;
         if (tid < 32) wl[EW_VEC + i] = reinterpret_cast<const u32x4 *>(a.b2)[i];
         else if (tid >= 64 && tid < 96) wl[EW_VEC + 32 + i] = reinterpret_cast<const u32x4 *>(a.b3)[i];
@@ -181,22 +155,25 @@ __global__ __launch_bounds__(EW_WAVES * 64, 2) void upd_wide_kernel(EdgeTileArgs
             cf[96 + i] = make_float4(g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w);
         }
     }
-    __syncthreads();
-    for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        const int2 tn = a.tile_list[t];
-        const int4 info = a.node_info[tn.x];
+    int grid = gridDim.x;
+    PIN1(grid);
+    for (int t = blockIdx.x; t < n_tiles; t += grid) {
+        const int2 tn = scalar_load(tile_list + t);
+        const int4 info = scalar_load(node_info + tn.x);
         const int n = tn.x, src = info.x, base = info.y, K = info.z;
         const int col = 32 * tn.y + c;
         const bool valid = col < K;
         const int colc = valid ? col : 0;
-        const int j = a.E_idx[(size_t)src * 64 + colc];
+        const int j = E_idx[(size_t)src * 64 + colc];
+        if (!HOISTED) w1.start(W1h, bo, lane);
+        else w3.start(W3h, bo, lane);
         f32x16 xq, acc, pq;
-        edge_quarter_load(xq, a.hE_in + (size_t)(a.in_by_src ? src : n) * EDGE_BLOCK, colc, bo, h);   // operand and residual
-        quarter_load(acc, a.Q + (size_t)(base + j) * HD, bo, h);
-        quarter_load(pq, a.P + (size_t)n * HD, bo, h);
+        edge_quarter_load(xq, hE_in + (size_t)(in_by_src ? src : n) * EDGE_BLOCK, colc, bo, h);   // operand and residual
+        quarter_load(acc, Q + (size_t)(base + j) * HD, bo, h);
+        quarter_load(pq, P + (size_t)n * HD, bo, h);
         if (HOISTED) {
             f32x16 e1;
-            edge_quarter_load(e1, a.E1 + (size_t)src * EDGE_BLOCK, colc, bo, h);
+            edge_quarter_load(e1, E1 + (size_t)src * EDGE_BLOCK, colc, bo, h);
             acc += pq;
             acc += e1;
         } else {
@@ -204,23 +181,23 @@ __global__ __launch_bounds__(EW_WAVES * 64, 2) void upd_wide_kernel(EdgeTileArgs
             acc += pq;
             __syncthreads();
             w1.run<TERMS>(acc, fragX, lane);                                   // layer 1
-            w3.start(a.W3h, bo, lane);
+            w3.start(W3h, bo, lane);
         }
-        publish_quarter<true>(fragA, acc, bo, lane, a.gelu_a);
+        publish_quarter<true>(fragA, acc, bo, lane, gelu_a);
+        __syncthreads();
         f32x16 t2;
         quarter_load(t2, c_b2, bo, h);
-        __syncthreads();
         w2.run<TERMS>(t2, fragA, lane);                                        // layer 2 on GELU(layer 1)
-        publish_quarter<true>(fragB, t2, bo, lane, a.gelu_b);
+        publish_quarter<true>(fragB, t2, bo, lane, gelu_b);
         // layer 3 accumulates onto (h_E + b13) * 2^E (c_b3 holds b13 * 2^E)
-        quarter_unsplit_scale_add_row(xq, a.res_scale, c_b3, bo, h);
+        quarter_unsplit_scale_add_row(xq, res_scale, c_b3, bo, h);
         __syncthreads();
         w3.run<TERMS>(xq, fragB, lane);                                        // layer 3 on GELU(layer 2)
         xch_write(xch, xq, bo, h, c);
         __syncthreads();
-        xch_layernorm_affine(xq, xch, a.ln_eps, c_modA, c_modB, bo, h, c);
+        xch_layernorm_affine(xq, xch, ln_eps, c_modA, c_modB, bo, h, c);
         quarter_presplit(xq);
-        if (valid) edge_quarter_store(xq, a.hE_out + (size_t)n * EDGE_BLOCK, col, bo, h);
+        if (valid) edge_quarter_store(xq, hE_out + (size_t)n * EDGE_BLOCK, col, bo, h);
     }
 }
 
@@ -229,24 +206,37 @@ __global__ __launch_bounds__(EW_WAVES * 64, 2) void upd_wide_kernel(EdgeTileArgs
 template <bool HOISTED, int TERMS>
 __global__ __launch_bounds__(EW_WAVES * 64, 2) void msg_wide_kernel(EdgeTileArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
+    const int2 *tile_list = a.tile_list;
+    const int4 *node_info = a.node_info;
+    const int32_t *E_idx = a.E_idx;
+    const float *xsrc = HOISTED ? a.E1 : a.hE_in;    // layer-1 edge operand: hoisted term or h_E
+    const float *P = a.P, *Q = a.Q, *b2 = a.b2;
+    float *S = a.S;
+    const void *W1h = a.W1h, *W2h = a.W2h;
+    int n_tiles = a.n_tiles, n_nodes = a.n_nodes, in_by_src = a.in_by_src;
+    GeluK gelu_a = a.gelu_a, gelu_b = a.gelu_b;
+    PIN_PTR(tile_list); PIN_PTR(node_info); PIN_PTR(E_idx); PIN_PTR(xsrc); PIN_PTR(P); PIN_PTR(Q); PIN_PTR(b2); PIN_PTR(S);
+    PIN_PTR(W1h); PIN_PTR(W2h); PIN1(n_tiles); PIN1(n_nodes); PIN1(in_by_src);
+    pin_gelu(gelu_a); pin_gelu(gelu_b);
     u32x4 *fragX = wl + EW_FRAG_X, *fragA = wl + EW_FRAG_A;
     const int tid = threadIdx.x, lane = tid & 63, bo = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     BlockQuarter w1, w2;
-    if (!HOISTED) w1.start(a.W1h, bo, lane);
-    w2.start(a.W2h, bo, lane);
-    const float bias = a.b2[32 * bo + c];
-    const float *xsrc = HOISTED ? a.E1 : a.hE_in;    // layer-1 edge operand: hoisted term or h_E
-    for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        const int2 tn = a.tile_list[t];
-        const int4 info = a.node_info[tn.x];
+    if (!HOISTED) w1.start(W1h, bo, lane);
+    w2.start(W2h, bo, lane);
+    const float bias = b2[32 * bo + c];
+    int grid = gridDim.x;
+    PIN1(grid);
+    for (int t = blockIdx.x; t < n_tiles; t += grid) {
+        const int2 tn = scalar_load(tile_list + t);
+        const int4 info = scalar_load(node_info + tn.x);
         const int n = tn.x, half = tn.y, src = info.x, base = info.y, K = info.z;
         const int colc = (32 * half + c < K) ? 32 * half + c : 0;
-        const int j = a.E_idx[(size_t)src * 64 + colc];
+        const int j = E_idx[(size_t)src * 64 + colc];
         f32x16 xq, acc, pq;
-        edge_quarter_load(xq, xsrc + (size_t)((HOISTED || a.in_by_src) ? src : n) * EDGE_BLOCK, colc, bo, h);
-        quarter_load(acc, a.Q + (size_t)(base + j) * HD, bo, h);
-        quarter_load(pq, a.P + (size_t)n * HD, bo, h);
+        edge_quarter_load(xq, xsrc + (size_t)((HOISTED || in_by_src) ? src : n) * EDGE_BLOCK, colc, bo, h);
+        quarter_load(acc, Q + (size_t)(base + j) * HD, bo, h);
+        quarter_load(pq, P + (size_t)n * HD, bo, h);
         if (HOISTED) {
             acc += pq;
             acc += xq;
@@ -256,7 +246,7 @@ __global__ __launch_bounds__(EW_WAVES * 64, 2) void msg_wide_kernel(EdgeTileArgs
             __syncthreads();
             w1.run<TERMS>(acc, fragX, lane);                                   // layer 1 (pre-split h_E tile)
         }
-        publish_quarter<true>(fragA, acc, bo, lane, a.gelu_a);
+        publish_quarter<true>(fragA, acc, bo, lane, gelu_a);
         f32x16 t2;
         {
             float bv = bias;
@@ -271,7 +261,7 @@ __global__ __launch_bounds__(EW_WAVES * 64, 2) void msg_wide_kernel(EdgeTileArgs
             f32x2 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = f32x2{t2[r + 2 * i], t2[r + 2 * i + 1]};
-            gelu_pairs<4>(v, a.gelu_b);
+            gelu_pairs<4>(v, gelu_b);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 t2[r + 2 * i] = v[i].x;
@@ -289,7 +279,7 @@ __global__ __launch_bounds__(EW_WAVES * 64, 2) void msg_wide_kernel(EdgeTileArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) s0 += ((r & 3) + 8 * (r >> 2) + 4 * h < cnt) ? t2[r] : 0.f;
         }
-        a.S[((size_t)(half + 2 * h) * a.n_nodes + n) * HD + 32 * bo + c] = s0;
+        S[((size_t)(half + 2 * h) * n_nodes + n) * HD + 32 * bo + c] = s0;
         // HOISTED has no barrier between the fragment write above and the next tile's: the slowest wave may still be
         // reading this tile's fragments
         if (HOISTED) __syncthreads();

@@ -13,19 +13,19 @@ torch.set_grad_enabled(False)
 den = Denoiser(synth.denoiser_state_dict(1234), "cuda:0")
 names = ["loads + publish S -> barrier", "W3 + xch -> barrier", "LN1 + publish -> barrier", "W_in x2 + publish -> barrier",
          "W_out x4 + xch -> barrier", "LN2", "store h_V, publish -> barrier", "projections + stores issued", "stores drained",
-         "  phase 1: weight quarters requested", "  phase 1: node_info arrived", "  phase 1: S / h_V rows arrived, summed",
-         "  phase 1: S published", "  phase 1: barrier"]
+         "  phase 1: to the staging code's end", "  phase 1: S published, barrier",
+         "    start -> all loads issued", "    node_info arrived", "    S planes arrived", "    h_V quarter arrived", "    W3, W_in 0 quarters arrived"]
 for L in (87, 300):
     p = synth.make_protein(L, 50, n_frames=1)
     st = den.prepare_structures([torch.from_numpy(p["xyz_full"])[0, 1:-1]], [torch.from_numpy(p["z_full"])[1:-1]])
     job = den.make_job(st, [0])
     x = torch.randn(job.n_nodes, 3, device="cuda")
-    acc = torch.zeros(14, dtype=torch.float64)
+    acc = torch.zeros(16, dtype=torch.float64)
     n = 20
     for _ in range(n):
         den.forward(job, x, 500)
         torch.cuda.synchronize()
-        acc += job.hV[0, :14].double().cpu()
+        acc += job.hV[0, :16].double().cpu()
     acc /= n
     tot = acc[:9].sum()
     print(f"L = {L}: {tot:.0f} s_memtime ticks per launch")
