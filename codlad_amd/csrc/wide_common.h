@@ -89,24 +89,24 @@ template <bool GELU>
 DEV void publish_quarter(u32x4 *frag, f32x16 q, int bo, int lane, const GeluK &gk) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+        // the four pairs of a k-step side by side (gelu_pairs<4>: the dependent Horner steps of one pair are separated by
+        // those of the others; one pair at a time a publish took ~2 800 cycles for 16 values, tools/node_wide_stamps.py)
+        f32x2 x[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) x[p] = f32x2{q[8 * s + 2 * p], q[8 * s + 2 * p + 1]};
+        if (GELU) gelu_pairs<4>(x, gk);
         SplitFrag f;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            f32x2 x = {q[8 * s + 2 * p], q[8 * s + 2 * p + 1]};
-            if (GELU) {
-                f32x2 t[1] = {x};
-                gelu_pairs<1>(t, gk);
-                x = t[0];
-            }
-            const f16x2 hh = __builtin_convertvector(x, f16x2);
-            const f16x2 ll = split_lo_pair(hh, x);
+            const f16x2 hh = __builtin_convertvector(x[p], f16x2);
+            const f16x2 ll = split_lo_pair(hh, x[p]);
             f.hi[2 * p] = hh.x; f.hi[2 * p + 1] = hh.y;
             f.lo[2 * p] = ll.x; f.lo[2 * p + 1] = ll.y;
         }
         frag[((2 * bo + s) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, f.hi);
         frag[((2 * bo + s) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, f.lo);
-        // one k-step's four pairs at a time: interleaving all eight activations costs ~50 registers, which these kernels
-        // (two or three weight quarters resident) do not have
+        // one k-step at a time: interleaving both costs registers these kernels (two or three weight quarters resident)
+        // do not have
         __builtin_amdgcn_sched_barrier(0);
     }
 }
