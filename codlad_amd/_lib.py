@@ -152,7 +152,7 @@ def lib():
     return _lib
 
 
-OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT, OPT_TP_CONV_VARIANT, OPT_EDGE_UPD_VARIANT, OPT_EDGE_CUS, OPT_EDGE_WIDE_MAX_TILES = 0, 1, 3, 4, 5, 6, 7   # CODLAD_OPT_* of include/codlad_hip.h
+OPT_NODEQ_MAX_TILES, OPT_EDGE_TILE_MAX_NODES, OPT_DEC_EDGE_VARIANT, OPT_TP_CONV_VARIANT, OPT_EDGE_UPD_VARIANT, OPT_EDGE_CUS, OPT_EDGE_WIDE_MAX_TILES, OPT_NODE_QUAD_MAX_TILES = 0, 1, 3, 4, 5, 6, 7, 2   # CODLAD_OPT_* of include/codlad_hip.h
 
 
 def set_option(option, value):

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcodlad_hip.so")
 SOURCES = ["api.hip", "denoiser_kernels.hip", "edge_msg_kernel.hip", "edge_upd_kernel.hip", "edge_upd1_kernel.hip", "edge_tile_kernels.hip",
            "edge_wide_kernels.hip",
-           "node_wide_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
+           "node_wide_kernels.hip", "node_quad_kernels.hip", "ode_kernels.hip", "features_kernels.hip", "decode_kernels.hip",
            "ic_decoder_kernels.hip", "encoder_kernels.hip", "encoder_mfma_kernel.hip", "metrics_kernels.hip"]
 # Geometry / VQ kernels must round like the reference's unfused CPU ops (bit-exact neighbour lists
 # and code indices): no implicit FMA contraction there; intended FMAs are written as fmaf().
@@ -34,7 +34,8 @@ EXTRA_FLAGS = {"features_kernels.hip": ["-ffp-contract=off"], "ode_kernels.hip":
                # AGPRs, ~450 v_accvgpr_read/write per tile around the vector work on them); the VGPR form keeps the
                # accumulators where GELU / LayerNorm read them, and the register-resident weights are placed in AGPRs by hand
                "edge_upd1_kernel.hip": ["-fno-slp-vectorize", "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "node_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
+               "node_wide_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"],
+               "node_quad_kernels.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "encoder_common.h"), os.path.join(CSRC, "edge_args.h"), os.path.join(CSRC, "node_args.h"),
            os.path.join(HERE, "..", "include", "codlad_hip.h")]
 

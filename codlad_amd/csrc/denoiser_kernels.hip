@@ -623,13 +623,18 @@ int edge_cus() {
     return v > 0 && v < num_cu() ? v : num_cu();
 }
 
-// node_wide_kernels.hip
+// node_wide_kernels.hip, node_quad_kernels.hip
 void launch_node_wide(int terms, bool upd, const NodeArgs &na, hipStream_t st);
+void launch_node_quad(int terms, const NodeArgs &na, hipStream_t st);
+// measured: 87 nodes 202 -> 182 us per step, the cfg-3 shard 476 -> 448, all of cfg 3 (411 tiles, two rounds) 2 316 -> 2 281;
+// cfg 2's half-jobs (553 tiles) lose 1.3 % against the streaming kernel, which reads every block once per 4-8 tiles
+static int node_quad_max_tiles() { return option_or(CODLAD_OPT_NODE_QUAD_MAX_TILES, "CODLAD_NODE_QUAD_MAX_TILES", 2 * num_cu()); }
 
 template <int TERMS>
 static void launch_node_h(bool upd, const NodeArgs &na, hipStream_t st) {
     const int tiles = (na.n_nodes + 31) / 32;
-    if (tiles <= nodeq_max_tiles()) launch_node_wide(TERMS, upd, na, st);
+    if (upd && tiles <= node_quad_max_tiles()) launch_node_quad(TERMS, na, st);
+    else if (tiles <= nodeq_max_tiles()) launch_node_wide(TERMS, upd, na, st);
     else if (tiles > 4 * num_cu()) launch_node_hw<TERMS, 8>(upd, na, st);
     else launch_node_hw<TERMS, 4>(upd, na, st);
 }

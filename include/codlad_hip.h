@@ -381,6 +381,8 @@ int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t 
  * variable of the same name (CODLAD_ prefix, upper case) sets the initial value.
  *   CODLAD_OPT_NODEQ_MAX_TILES   jobs of up to this many 32-node tiles run the node update on the small-job
  *                                "quarter" kernel (one tile per 4-wave workgroup), larger ones on the streaming one
+ *   CODLAD_OPT_NODE_QUAD_MAX_TILES  jobs of up to this many 32-node tiles run the node UPDATE on four waves per tile with the
+ *                                whole register file (a ring of six weight quarters in flight: node_quad_kernels.hip); same bits
  *   CODLAD_OPT_EDGE_TILE_MAX_NODES  jobs of up to this many nodes deal the edge kernels' work out per 32-edge
  *                                tile instead of per node (twice the waves for the same work)
  *   (slot 2 is unused: the round-2 header reserved it for a captured / persistent step loop that was never built)
@@ -398,6 +400,7 @@ int codlad_xyz_to_ic(const float *xyz, int n_frames, int n_atoms, const int32_t 
  *                                block each, weight quarters in registers: edge_wide_kernels.hip) instead of one; same bits */
 #define CODLAD_OPT_NODEQ_MAX_TILES 0
 #define CODLAD_OPT_EDGE_TILE_MAX_NODES 1
+#define CODLAD_OPT_NODE_QUAD_MAX_TILES 2
 #define CODLAD_OPT_DEC_EDGE_VARIANT 3
 #define CODLAD_OPT_TP_CONV_VARIANT 4
 #define CODLAD_OPT_EDGE_UPD_VARIANT 5

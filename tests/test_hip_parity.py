@@ -18,6 +18,7 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 EDGE_WIDE_DEFAULT = 22 * 256      # CODLAD_OPT_EDGE_WIDE_MAX_TILES as shipped (22 x the CU count)
+NODE_QUAD_DEFAULT = 2 * 256      # CODLAD_OPT_NODE_QUAD_MAX_TILES as shipped (twice the CU count)
 EDGE_UPD_DEFAULT = 0      # the library's default CODLAD_OPT_EDGE_UPD_VARIANT
 
 
@@ -598,21 +599,28 @@ def test_small_job_node_kernel_is_bit_identical_to_the_streaming_one(sd):
     operands exchanged as split fragments through LDS) computes exactly what the streaming kernel does: same
     per-element code, same accumulation order."""
     outs = []
-    for max_tiles in (0, 1 << 20):
+    # streaming kernel | eight waves per tile (node_kernel_w) | four waves per tile with a ring of weight quarters (node_kernel_q)
+    for max_tiles, quad_tiles in ((0, 0), (1 << 20, 0), (1 << 20, 1 << 20)):
         _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, max_tiles)
+        _lib.set_option(_lib.OPT_NODE_QUAD_MAX_TILES, quad_tiles)
         try:
-            d = Denoiser(sd, DEV, precision="f16x3")
-            pa, pb = synth.make_protein(40, 5, n_frames=1), synth.make_protein(87, 6, n_frames=1)
-            st = d.prepare_structures([torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in (pa, pb)],
-                                      [torch.from_numpy(p["z_full"])[1:-1] for p in (pa, pb)])
-            job = d.make_job(st, [0, 1, 1])
-            x = synth.gaussian((40 + 87 + 87, 3), 99).to(DEV)
-            T = 5
-            eps = synth.gaussian((T, 214, 3), 98).to(DEV)
-            outs.append((d.forward(job, x, 700), d.sample(job, x, eps, tables(T))))
+            for precision in ("f16x3", "f16x4"):
+                d = Denoiser(sd, DEV, precision=precision)
+                pa, pb = synth.make_protein(40, 5, n_frames=1), synth.make_protein(87, 6, n_frames=1)
+                st = d.prepare_structures([torch.from_numpy(p["xyz_full"])[0, 1:-1] for p in (pa, pb)],
+                                          [torch.from_numpy(p["z_full"])[1:-1] for p in (pa, pb)])
+                job = d.make_job(st, [0, 1, 1])
+                x = synth.gaussian((40 + 87 + 87, 3), 99).to(DEV)
+                T = 5
+                eps = synth.gaussian((T, 214, 3), 98).to(DEV)
+                outs.append((d.forward(job, x, 700), d.sample(job, x, eps, tables(T))))
         finally:
             _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, 256)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            _lib.set_option(_lib.OPT_NODE_QUAD_MAX_TILES, NODE_QUAD_DEFAULT)
+    for v in (1, 2):
+        for k in range(2):
+            assert bool(torch.isfinite(outs[k][0]).all())
+            assert torch.equal(outs[k][0], outs[2 * v + k][0]) and torch.equal(outs[k][1], outs[2 * v + k][1]), (v, k)
 
 
 def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
@@ -632,6 +640,7 @@ def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
         _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, max_nodes)
         _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, wide_tiles)
         _lib.set_option(_lib.OPT_EDGE_WIDE_MAX_TILES, 0)      # the one-wave tile kernels (the four-wave ones: next test)
+        _lib.set_option(_lib.OPT_NODE_QUAD_MAX_TILES, 0)      # node update: streaming or eight-wave kernel as NODEQ says
         try:
             d = Denoiser(sd, DEV, precision="f16x3")
             job = d.make_job(d.prepare_structures(xyz, zz), list(range(len(lens))))
@@ -644,6 +653,7 @@ def test_small_job_tilewise_edge_kernels_agree_with_per_node_order(sd):
             _lib.set_option(_lib.OPT_EDGE_TILE_MAX_NODES, 1 << 30)
             _lib.set_option(_lib.OPT_NODEQ_MAX_TILES, 256)
             _lib.set_option(_lib.OPT_EDGE_WIDE_MAX_TILES, EDGE_WIDE_DEFAULT)
+            _lib.set_option(_lib.OPT_NODE_QUAD_MAX_TILES, NODE_QUAD_DEFAULT)
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
     off = np.concatenate([[0], np.cumsum(lens)])

@@ -322,6 +322,10 @@ def test_hot_edge_kernels_keep_their_register_budget():
             assert r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (name, r)
         if "upd_wide_kernel" in name:
             assert r["ScratchSize"] <= 64 and r["Occupancy"] == 2, (name, r)
+        # the four-wave node update owns the whole register file; its ring of weight quarters overflows into accumulator
+        # registers, never into scratch
+        if "node_kernel_q" in name:
+            assert r["ScratchSize"] == 0 and r["Occupancy"] == 1, (name, r)
 
 
 @pytest.mark.parametrize("name", list(cases.INFO_CASES))
