@@ -6,8 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${TAG}_small_jobs.txt
 {
-echo "# tools/small_job_latency.py, build as shipped (four-wave edge kernels up to 22 x 256 tiles, device-side kernel arguments)"
+echo "# tools/small_job_latency.py, build as shipped (four-wave edge kernels up to 22 x 256 tiles, four-wave node update up to 2 x 256 tiles, device-side kernel arguments)"
 timeout -k 10 300 python tools/small_job_latency.py 2>/dev/null
+echo "# CODLAD_NODE_QUAD_MAX_TILES=0 (node update on node_kernel_w, eight waves per tile, instead of node_kernel_q)"
+CODLAD_NODE_QUAD_MAX_TILES=0 timeout -k 10 300 python tools/small_job_latency.py 2>/dev/null
 echo "# CODLAD_EDGE_WIDE_MAX_TILES=0 (one-wave tile kernels / per-node kernels, as in round 3; node kernel and arguments as shipped)"
 CODLAD_EDGE_WIDE_MAX_TILES=0 timeout -k 10 300 python tools/small_job_latency.py 2>/dev/null
 echo "# HIP_FORCE_DEV_KERNARG=0 (kernel arguments in host memory, the runtime's default)"
