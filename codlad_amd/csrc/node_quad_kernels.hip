@@ -37,9 +37,19 @@ __device__ constexpr int quad_block(int k) {
     return order[k];
 }
 
+#ifdef NQ_STAMP      // diagnostic build (tools/node_quad_stamps.py): phase stamps of workgroup 0's first wave, left in PQ[0][0][0..]
+#define NQ_MARK(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NQ_MARK(i) do {} while (0)
+#endif
+
 template <int TERMS>
 __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) {
     extern __shared__ __align__(16) u32x4 wl[];
+#ifdef NQ_STAMP
+    unsigned long long stamp[12] = {};
+#endif
+    NQ_MARK(0);
     u32x4 *fragA = wl + Q_FRAG_A, *fragB = wl + Q_FRAG_B;
     float4 *xch = reinterpret_cast<float4 *>(wl + Q_XCH);
     const float *modAB = reinterpret_cast<const float *>(wl + Q_MOD);
@@ -54,6 +64,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
                  : "s"(a.proj_flags[0]), "s"(a.proj_flags[1]), "s"(a.proj_flags[2]), "s"(a.proj_flags[3]), "s"(a.b3), "s"(a.b_in),
                    "s"(a.b_out), "s"(a.proj_b[0]), "s"(a.proj_b[1]), "s"(a.proj_b[2]), "s"(a.proj_b[3]), "s"(a.mods), "s"(a.s_scale),
                    "s"(a.blk_h[0]), "s"(a.blk_h[1]), "s"(a.blk_h[3]), "s"(a.blk_h[5]), "s"(a.blk_h[7]), "s"(a.blk_h[2]));
+    NQ_MARK(10);
     const int tid = threadIdx.x, lane = tid & 63, bo = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int node = blockIdx.x * 32 + c;
@@ -94,6 +105,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
     request(QK(0));
     request(QK(1));
     request(QK(2));
+    NQ_MARK(11);
     {   // small vectors -> LDS: slot 0 b3, 1-4 b_in, 5 b_out, 6-9 projection biases (zeros where absent)
         const int i = tid & 31;
         for (int sl = tid >> 5; sl < 10; sl += QUAD_WAVES * 2) {
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
     sq *= a.s_scale;
     publish_quarter<false>(fragA, sq, bo, lane, plain);
     __syncthreads();                                         // S fragments, staged vectors, modAB
+    NQ_MARK(1);
     {
         f32x16 q;
         quarter_load(q, lv, bo, h);
@@ -142,9 +155,11 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
         xch_write(xch, vq, bo, h, c);
     }
     __syncthreads();
+    NQ_MARK(2);
     xch_layernorm_affine(vq, xch, 1e-6f, modAB, modAB + HD, bo, h, c);
     publish_quarter<false>(fragA, vq, bo, lane, plain);
     __syncthreads();
+    NQ_MARK(3);
     // ---- phase B1: hidden chunk = GELU(W_in[chunk] @ v + b_in[chunk]) ---------------------------------------
     {
         f32x16 q;
@@ -154,6 +169,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
         quarter_load(q, lv + 2 * HD, bo, h);
         contract(QK(2), q, fragA);
         publish_quarter<true>(wl + Q_HID + 1 * FRAG_U4, q, bo, lane, a.gelu_ffn);
+        NQ_MARK(4);
         quarter_load(q, lv + 3 * HD, bo, h);
         contract(QK(3), q, fragA);
         publish_quarter<true>(wl + Q_HID + 2 * FRAG_U4, q, bo, lane, a.gelu_ffn);
@@ -162,6 +178,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
         publish_quarter<true>(wl + Q_HID + 3 * FRAG_U4, q, bo, lane, a.gelu_ffn);
     }
     __syncthreads();
+    NQ_MARK(5);
     // ---- phase B2: t = b_out + sum_ch W_out[ch] @ hidden[ch] (one accumulator, chunk after chunk) -----------
     {
         f32x16 q;
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
         xch_write(xch, vq, bo, h, c);
     }
     __syncthreads();
+    NQ_MARK(6);
     xch_layernorm_affine(vq, xch, 1e-6f, modAB + 2 * HD, modAB + 3 * HD, bo, h, c);
     // ---- new h_V: store, publish the projection inputs -------------------------------------------------------
     if (valid) {
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
         publish_quarter<false>(fragB, sum, bo, lane, plain);
     }
     __syncthreads();
+    NQ_MARK(7);
     // ---- phase C: the projections, one after the other ------------------------------------------------------
     auto project = [&](auto pc) {
         constexpr int p = decltype(pc)::value;
@@ -207,6 +226,17 @@ __global__ __launch_bounds__(QUAD_WAVES * 64, 1) void node_kernel_q(NodeArgs a) 
     if (1 < n_proj) project(QK(1));
     if (2 < n_proj) project(QK(2));
     if (3 < n_proj) project(QK(3));
+#ifdef NQ_STAMP
+    NQ_MARK(8);
+    __builtin_amdgcn_s_waitcnt(0);
+    NQ_MARK(9);
+    // (of the launches WITH projections: the decoder's last update has none and would hide that phase)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_proj > 0) {
+        for (int i = 0; i < 9; ++i) a.proj_out[0][i] = (float)(stamp[i + 1] - stamp[i]);
+        a.proj_out[0][9] = (float)(stamp[10] - stamp[0]); a.proj_out[0][10] = (float)(stamp[11] - stamp[10]);
+        a.proj_out[0][11] = (float)(stamp[1] - stamp[11]);
+    }
+#endif
 #undef QK
 }
 
