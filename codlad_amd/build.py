@@ -60,7 +60,9 @@ def record_resources(source, remarks):
     if os.path.exists(RESOURCES):
         with open(RESOURCES) as f:
             table = json.load(f)
-    table = {k: v for k, v in table.items() if v.get("source") != source}
+    # this source's old entries go, and those of sources that are no longer built (an experiment's leftovers would be
+    # held to the budgets of kernels with similar names)
+    table = {k: v for k, v in table.items() if v.get("source") != source and v.get("source") in SOURCES}
     cur = None
     for line in remarks.splitlines():
         m = re.search(r"remark: Function Name: (\S+)", line)
