@@ -31,6 +31,9 @@ import time
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import codlad_amd  # noqa: E402,F401  (before the first HIP call: the package asks the runtime for device-side kernel arguments)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import codlad_amd  # noqa: E402,F401  (as every entry point does: before the first HIP call, see codlad_amd/__init__.py)
+
 torch.set_grad_enabled(False)
 
 

@@ -395,3 +395,19 @@ def test_job_parts_deal_the_samples_and_share_the_edge_state():
             assert sub.hE.data_ptr() == job.hE[start:start + sub.n_nodes].data_ptr() and sub.hE.is_contiguous()
             start += sub.n_nodes
         assert start == job.n_nodes and bool((seen == 1).all())
+
+
+def test_package_asks_for_device_side_kernel_arguments_unless_told_otherwise():
+    """`import codlad_amd` sets HIP_FORCE_DEV_KERNARG=1 if the caller has not set it (the runtime reads it at its first
+    call; 17 short launches per DDPM step of a small job each start with a read of the argument segment), and leaves a
+    caller's value alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, codlad_amd; print(os.environ['HIP_FORCE_DEV_KERNARG'])"
+    for given, want in ((None, "1"), ("0", "0")):
+        env = {k: v for k, v in os.environ.items() if k != "HIP_FORCE_DEV_KERNARG"}
+        if given is not None:
+            env["HIP_FORCE_DEV_KERNARG"] = given
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True)
+        assert out.stdout.strip() == want
