@@ -14,7 +14,7 @@ for c in cfg3 cfg4share; do python3 bench.py --steps 2 --warmup 1 --config $c > 
 python3 bench.py --config cfg5 > $OUT/bench_cfg5.json 2>/dev/null; echo "bench cfg5 done"
 python3 tools/two_stream_probe.py 2 > $OUT/two_stream_probe.txt 2>/dev/null
 python3 tools/small_job_latency.py > $OUT/small_jobs.txt 2>/dev/null
-CODLAD_EDGE_TILE_MAX_NODES=0 CODLAD_NODEQ_MAX_TILES=0 python3 tools/small_job_latency.py > $OUT/small_jobs_round1_kernels.txt 2>/dev/null
+CODLAD_EDGE_TILE_MAX_NODES=0 CODLAD_NODEQ_MAX_TILES=0 CODLAD_EDGE_WIDE_MAX_TILES=0 CODLAD_NODE_QUAD_MAX_TILES=0 python3 tools/small_job_latency.py > $OUT/small_jobs_round1_kernels.txt 2>/dev/null
 echo "small jobs done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-leg --no-cfg5 --streams 1 > $OUT/trace.log 2>&1
 python3 tools/kernel_stats.py $OUT/trace > $OUT/kernel_stats.txt
