@@ -19,6 +19,7 @@ ap.add_argument("--only", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--sweep", action="store_true", help="k copies of one 87-residue protein, k = 1 .. 24, instead of the four cases")
 ap.add_argument("--ks", default="", help="--sweep: comma-separated copy counts")
+ap.add_argument("--streams", type=int, default=None, help="Denoiser.sample(streams=...): the job as this many part-jobs on as many HIP streams")
 args = ap.parse_args()
 
 torch.set_grad_enabled(False)
@@ -41,11 +42,11 @@ for k, (label, lens) in enumerate(CASES):
     job = den.make_job(st, list(range(len(lens))))
     xT = torch.randn(job.n_nodes, 3, device="cuda")
     eps = torch.randn(100, job.n_nodes, 3, device="cuda")
-    den.sample(job, xT, eps, tb)
+    den.sample(job, xT, eps, tb, streams=args.streams)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        den.sample(job, xT, eps, tb)
+        den.sample(job, xT, eps, tb, streams=args.streams)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps
     print(f"{label:48s} {job.n_nodes:6d} nodes: {dt * 1e3:8.2f} ms per 100-step loop = {dt / 100 * 1e6:7.1f} us/step, "
